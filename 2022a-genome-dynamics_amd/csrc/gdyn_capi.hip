@@ -1,0 +1,849 @@
+// gdyn_capi.hip -- host side of libgdyn: the C-ABI of include/gdyn.h over the HIP kernels.
+//
+// One handle = one HIP device + one stream + R replicas of an N-bead system resident in HBM.
+// gd_run() enqueues   [list build] + K x k_step   segments with no host round trip; the
+// Verlet skin is VERIFIED on the device (every step checks each bead's displacement since
+// the build) and a violated chunk is rolled back and re-run with a shorter interval, so
+// the fixed build cadence never changes results (only the summation order of pair terms).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gdyn.h"
+#include "gdyn_types.h"
+
+// ------------------------------------------------------------------ errors
+
+static thread_local char g_err[1024];
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(call)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return fail(GD_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define GDCHK(call)              \
+    do {                         \
+        int rc_ = (call);        \
+        if (rc_ != GD_OK) return rc_; \
+    } while (0)
+
+extern "C" const char *gd_last_error(void) { return g_err; }
+extern "C" const char *gd_backend_name(void) { return "hip"; }
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t resize(size_t count, bool zero = true)
+    {
+        if (count == n && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }
+        n = count;
+        if (zero) { e = hipMemset(p, 0, count * sizeof(T)); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+        return e;
+    }
+};
+
+// ------------------------------------------------------------------ system
+
+struct Bond { uint32_t i, j; int type; };
+struct BendRange { uint32_t start, end; double energy; int per_bead; };
+struct PointSource { int kind; double k, b, p[3]; std::vector<uint8_t> mask; };
+struct DynSet { bool used = false; gd_bond_params p; std::vector<uint32_t> pairs; };
+
+struct gd_system {
+    uint32_t N = 0, R = 0, Np = 0, nblk = 0;
+    int device = 0, box_kind = 0;
+    double box[3] = {0, 0, 0};
+    hipStream_t stream = nullptr;
+
+    // host model
+    std::vector<double> a, b, mob, bend;
+    bool has_pair = false; gd_pair_softcore pair{};
+    std::vector<gd_bond_params> btypes; std::vector<int> bterm;
+    std::vector<Bond> bonds;
+    DynSet dyn[4];
+    std::vector<BendRange> bends;
+    std::vector<PointSource> psrc;
+    bool has_wall = false; gd_wall wall{};
+    bool has_scaling = false; double bs_init = 1, bs_tau = 1, bo_init = 1, bo_tau = 1;
+    std::vector<DevCtx> hctx;      // host mirror of the device context
+
+    bool topo_dirty = true, list_valid = false, ctx_dirty = true;
+    bool has_bend = false, has_bonds = false;
+    uint32_t WB = 0, W = 0, ncell_cap = 0;
+    int pcur = 0, ccur = 0;
+
+    // tuning / cadence
+    double skin = 0.5;
+    uint32_t K = 4, adapt = 1, use_graph = 0;
+    uint32_t steps_since_build = 0;
+    float rv = 0;
+    uint64_t rebuilds = 0, rollbacks = 0;
+    std::vector<unsigned long long> lcount;
+    gd_timing timing{};
+
+    // device: static (bead order)
+    DevBuf<float2> ab_o; DevBuf<float> mob_o; DevBuf<float4> bendE_o; DevBuf<unsigned char> psmask_o, bdeg_o;
+    DevBuf<unsigned> badj_o; DevBuf<int4> chain_o; DevBuf<BondType> btab;
+    // device: per slot
+    DevBuf<float4> pos[2], xb, fout, snap;
+    DevBuf<unsigned> orig[2], slot_of, cell_id, rank, cell_cnt, cell_start, nbr, ncnt, badj, flags;
+    DevBuf<float> bbox;
+    DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<unsigned char> psmask, bdeg; DevBuf<int4> chain;
+    DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part; DevBuf<double> epart;
+    DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
+    int ocur = 0;   // which orig[] buffer is current
+    std::vector<hipEvent_t> events;
+    ~gd_system()
+    {
+        for (auto e : events) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static int valid_pq(int p, int q) { return (p == 2 || p == 4 || p == 6 || p == 8 || p == 12) && q >= 1 && q <= 4; }
+
+extern "C" int gd_create(const gd_desc *d, gd_system **out)
+{
+    if (!d || !out) return fail(GD_EINVAL, "gd_create: NULL argument");
+    if (d->n_beads == 0 || d->n_replicas == 0) return fail(GD_EINVAL, "gd_create: n_beads and n_replicas must be > 0");
+    if (d->n_beads > GD_ADJ_MASK) return fail(GD_EINVAL, "gd_create: n_beads exceeds %u", GD_ADJ_MASK);
+    if (d->box_kind != GD_BOX_OPEN && d->box_kind != GD_BOX_PERIODIC) return fail(GD_EINVAL, "gd_create: bad box_kind");
+    if (d->box_kind == GD_BOX_PERIODIC)
+        for (int k = 0; k < 3; k++) if (!(d->box[k] > 0)) return fail(GD_EINVAL, "gd_create: periodic box needs positive periods");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GD_ENODEVICE, "gd_create: no HIP device visible (libgdyn has no CPU fallback)");
+    if (d->device < 0 || d->device >= ndev) return fail(GD_ENODEVICE, "gd_create: device %d not in [0,%d)", d->device, ndev);
+    HIPCHK(hipSetDevice(d->device));
+    gd_system *s = new (std::nothrow) gd_system();
+    if (!s) return fail(GD_ENOMEM, "gd_create: out of host memory");
+    s->N = d->n_beads; s->R = d->n_replicas; s->device = d->device; s->box_kind = d->box_kind;
+    memcpy(s->box, d->box, sizeof s->box);
+    s->nblk = (s->N + GD_BLOCK - 1) / GD_BLOCK;
+    s->Np = s->nblk * GD_BLOCK;
+    s->a.assign(s->N, 0.0); s->b.assign(s->N, 0.0); s->mob.assign(s->N, 1.0); s->bend.assign(s->N, 0.0);
+    s->hctx.assign(s->R, DevCtx{});
+    for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; c.semi[0] = c.semi[1] = c.semi[2] = 1; }
+    s->lcount.assign(s->R, 0ull);
+    s->ncell_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8ull * s->N, 4096ull), 262144ull);
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return fail(GD_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    const size_t RNp = (size_t)s->R * s->Np, RN = (size_t)s->R * s->N;
+    bool ok = true;
+    for (int k = 0; k < 2; k++) {
+        ok = ok && s->pos[k].resize(RNp) == hipSuccess && s->orig[k].resize(RNp) == hipSuccess && s->ctx[k].resize(s->R) == hipSuccess;
+    }
+    ok = ok && s->xb.resize(RNp) == hipSuccess && s->slot_of.resize(RN) == hipSuccess && s->cell_id.resize(RNp) == hipSuccess &&
+         s->rank.resize(RNp) == hipSuccess && s->cell_cnt.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess &&
+         s->cell_start.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess && s->ncnt.resize(RNp) == hipSuccess &&
+         s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
+         s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->bendE.resize(RNp) == hipSuccess &&
+         s->psmask.resize(RNp) == hipSuccess && s->bdeg.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
+         s->react_part.resize((size_t)s->R * s->nblk) == hipSuccess && s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
+         s->lcount_d.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess;
+    if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
+    gd_launch_identity(s->orig[0].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) { delete s; return fail(GD_EHIP, "gd_create: identity kernel failed"); }
+    *out = s;
+    return GD_OK;
+}
+
+extern "C" int gd_destroy(gd_system *s)
+{
+    if (!s) return GD_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    delete s;
+    return GD_OK;
+}
+
+// ---------------------------------------------------------------- context
+
+static int upload_ctx(gd_system *s)
+{
+    if (!s->ctx_dirty) return GD_OK;
+    HIPCHK(hipMemcpyAsync(s->ctx[s->ccur].p, s->hctx.data(), s->R * sizeof(DevCtx), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->ctx_dirty = false;
+    return GD_OK;
+}
+static int download_ctx(gd_system *s)
+{
+    HIPCHK(hipMemcpyAsync(s->hctx.data(), s->ctx[s->ccur].p, s->R * sizeof(DevCtx), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return GD_OK;
+}
+
+// ---------------------------------------------------------- model setters
+
+extern "C" int gd_set_positions(gd_system *s, const double *xyz)
+{
+    if (!s || !xyz) return fail(GD_EINVAL, "gd_set_positions: NULL argument");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t RN = (size_t)s->R * s->N;
+    std::vector<float4> h(RN);
+    for (size_t i = 0; i < RN; i++) {
+        if (!std::isfinite(xyz[3 * i]) || !std::isfinite(xyz[3 * i + 1]) || !std::isfinite(xyz[3 * i + 2]))
+            return fail(GD_EINVAL, "gd_set_positions: non-finite coordinate at %zu", 3 * i);
+        h[i] = make_float4((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.f);
+    }
+    HIPCHK(hipMemcpy2DAsync(s->pos[s->pcur].p, (size_t)s->Np * sizeof(float4), h.data(), (size_t)s->N * sizeof(float4),
+                            (size_t)s->N * sizeof(float4), s->R, hipMemcpyHostToDevice, s->stream));
+    gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->list_valid = false;
+    return GD_OK;
+}
+
+static int fetch_positions(gd_system *s, std::vector<float4> &h, int quantize)
+{
+    HIPCHK(hipSetDevice(s->device));
+    const size_t RN = (size_t)s->R * s->N;
+    h.resize(RN);
+    gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->fout.p, s->N, s->Np, s->R, quantize, s->stream);
+    HIPCHK(hipMemcpyAsync(h.data(), s->fout.p, RN * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return GD_OK;
+}
+
+extern "C" int gd_get_positions(gd_system *s, double *xyz)
+{
+    if (!s || !xyz) return fail(GD_EINVAL, "gd_get_positions: NULL argument");
+    std::vector<float4> h;
+    GDCHK(fetch_positions(s, h, 0));
+    for (size_t i = 0; i < h.size(); i++) { xyz[3 * i] = h[i].x; xyz[3 * i + 1] = h[i].y; xyz[3 * i + 2] = h[i].z; }
+    return GD_OK;
+}
+
+extern "C" int gd_get_positions_f32(gd_system *s, float *xyz, int quantize)
+{
+    if (!s || !xyz) return fail(GD_EINVAL, "gd_get_positions_f32: NULL argument");
+    std::vector<float4> h;
+    GDCHK(fetch_positions(s, h, quantize));
+    for (size_t i = 0; i < h.size(); i++) { xyz[3 * i] = h[i].x; xyz[3 * i + 1] = h[i].y; xyz[3 * i + 2] = h[i].z; }
+    return GD_OK;
+}
+
+extern "C" int gd_set_bead_params(gd_system *s, const double *a, const double *b, const double *mob, const double *bend)
+{
+    if (!s) return fail(GD_EINVAL, "gd_set_bead_params: NULL system");
+    if (mob) for (uint32_t i = 0; i < s->N; i++) if (!(mob[i] >= 0)) return fail(GD_EINVAL, "gd_set_bead_params: negative mobility at %u", i);
+    if (a) s->a.assign(a, a + s->N);
+    if (b) s->b.assign(b, b + s->N);
+    if (mob) s->mob.assign(mob, mob + s->N);
+    if (bend) s->bend.assign(bend, bend + s->N);
+    s->topo_dirty = true;
+    return GD_OK;
+}
+
+extern "C" int gd_set_pair_softcore(gd_system *s, const gd_pair_softcore *p)
+{
+    if (!s || !p) return fail(GD_EINVAL, "gd_set_pair_softcore: NULL argument");
+    if (!valid_pq(p->p_a, p->q_a) || !valid_pq(p->p_b, p->q_b)) return fail(GD_EINVAL, "gd_set_pair_softcore: unsupported softcore powers");
+    if (p->sigma_a < 0 || p->sigma_b < 0) return fail(GD_EINVAL, "gd_set_pair_softcore: negative diameter");
+    s->pair = *p; s->has_pair = true; s->list_valid = false;
+    return GD_OK;
+}
+
+static int check_bond_params(const gd_bond_params *p)
+{
+    if (p->kind < GD_POT_HARMONIC || p->kind > GD_POT_SOFTCORE) return fail(GD_EINVAL, "bond params: bad kind %d", p->kind);
+    if (p->kind == GD_POT_SOFTCORE && !valid_pq(p->p, p->q)) return fail(GD_EINVAL, "bond params: unsupported softcore powers");
+    return GD_OK;
+}
+
+static int add_bond_type(gd_system *s, const gd_bond_params *p, int term)
+{
+    for (size_t i = 0; i < s->btypes.size(); i++)
+        if (!memcmp(&s->btypes[i], p, sizeof *p) && s->bterm[i] == term) return (int)i;
+    if (s->btypes.size() >= GD_MAX_BOND_TYPES) return -1;
+    s->btypes.push_back(*p); s->bterm.push_back(term);
+    return (int)s->btypes.size() - 1;
+}
+
+extern "C" int gd_add_bond_range(gd_system *s, const gd_bond_params *p, uint32_t start, uint32_t end, uint32_t stride)
+{
+    if (!s || !p) return fail(GD_EINVAL, "gd_add_bond_range: NULL argument");
+    GDCHK(check_bond_params(p));
+    if (start > end || end > s->N) return fail(GD_EINVAL, "gd_add_bond_range: range [%u,%u) outside [0,%u)", start, end, s->N);
+    if (stride < 1 || stride > 2) return fail(GD_EINVAL, "gd_add_bond_range: stride must be 1 or 2");
+    const int t = add_bond_type(s, p, GD_TERM_BOND);
+    if (t < 0) return fail(GD_EINVAL, "gd_add_bond_range: too many bond parameter sets");
+    for (uint32_t i = start; i + stride < end; i++) s->bonds.push_back({i, i + stride, t});
+    s->topo_dirty = true;
+    return GD_OK;
+}
+
+extern "C" int gd_add_bond_pairs(gd_system *s, const gd_bond_params *p, const uint32_t *pairs, uint32_t n)
+{
+    if (!s || !p || (n && !pairs)) return fail(GD_EINVAL, "gd_add_bond_pairs: NULL argument");
+    GDCHK(check_bond_params(p));
+    for (uint32_t k = 0; k < n; k++)
+        if (pairs[2 * k] >= s->N || pairs[2 * k + 1] >= s->N || pairs[2 * k] == pairs[2 * k + 1])
+            return fail(GD_EINVAL, "gd_add_bond_pairs: bad pair %u (%u,%u)", k, pairs[2 * k], pairs[2 * k + 1]);
+    const int t = add_bond_type(s, p, GD_TERM_BOND);
+    if (t < 0) return fail(GD_EINVAL, "gd_add_bond_pairs: too many bond parameter sets");
+    for (uint32_t k = 0; k < n; k++) s->bonds.push_back({pairs[2 * k], pairs[2 * k + 1], t});
+    s->topo_dirty = true;
+    return GD_OK;
+}
+
+extern "C" int gd_set_dynamic_pairs(gd_system *s, uint32_t slot, const gd_bond_params *p, const uint32_t *pairs, uint32_t n)
+{
+    if (!s || !p || (n && !pairs)) return fail(GD_EINVAL, "gd_set_dynamic_pairs: NULL argument");
+    if (slot >= 4) return fail(GD_EINVAL, "gd_set_dynamic_pairs: slot %u out of range", slot);
+    GDCHK(check_bond_params(p));
+    for (uint32_t k = 0; k < n; k++)
+        if (pairs[2 * k] >= s->N || pairs[2 * k + 1] >= s->N || pairs[2 * k] == pairs[2 * k + 1])
+            return fail(GD_EINVAL, "gd_set_dynamic_pairs: bad pair %u", k);
+    s->dyn[slot].used = true; s->dyn[slot].p = *p;
+    s->dyn[slot].pairs.assign(pairs, pairs + 2 * (size_t)n);
+    s->topo_dirty = true;
+    return GD_OK;
+}
+
+extern "C" int gd_add_bending_range(gd_system *s, uint32_t start, uint32_t end, double energy, int per_bead)
+{
+    if (!s) return fail(GD_EINVAL, "gd_add_bending_range: NULL system");
+    if (start > end || end > s->N) return fail(GD_EINVAL, "gd_add_bending_range: range outside [0,N)");
+    s->bends.push_back({start, end, energy, per_bead});
+    s->topo_dirty = true;
+    return GD_OK;
+}
+
+extern "C" int gd_add_point_source(gd_system *s, int kind, double k, double b, const double point[3], const uint32_t *targets, uint32_t nt)
+{
+    if (!s || !point) return fail(GD_EINVAL, "gd_add_point_source: NULL argument");
+    if (kind != GD_POT_HARMONIC && kind != GD_POT_SEMISPRING && kind != GD_POT_SPRING) return fail(GD_EINVAL, "gd_add_point_source: unsupported kind");
+    if (s->psrc.size() >= GD_MAX_POINT_SOURCES) return fail(GD_EINVAL, "gd_add_point_source: at most %d sources", GD_MAX_POINT_SOURCES);
+    PointSource ps; ps.kind = kind; ps.k = k; ps.b = b; memcpy(ps.p, point, sizeof ps.p);
+    if (targets) {
+        for (uint32_t i = 0; i < nt; i++) if (targets[i] >= s->N) return fail(GD_EINVAL, "gd_add_point_source: target %u out of range", targets[i]);
+        ps.mask.assign(s->N, 0);
+        for (uint32_t i = 0; i < nt; i++) ps.mask[targets[i]] = 1;
+    }
+    s->psrc.push_back(std::move(ps));
+    s->topo_dirty = true;
+    return GD_OK;
+}
+
+extern "C" int gd_set_ellipsoid_wall(gd_system *s, const gd_wall *w)
+{
+    if (!s || !w) return fail(GD_EINVAL, "gd_set_ellipsoid_wall: NULL argument");
+    if (!valid_pq(w->p_a, w->q_a) || !valid_pq(w->p_b, w->q_b)) return fail(GD_EINVAL, "gd_set_ellipsoid_wall: unsupported softcore powers");
+    for (int k = 0; k < 3; k++) if (!(w->init_semiaxes[k] > 0)) return fail(GD_EINVAL, "gd_set_ellipsoid_wall: semiaxes must be positive");
+    s->wall = *w; s->has_wall = true;
+    for (auto &c : s->hctx) memcpy(c.semi, w->init_semiaxes, sizeof c.semi);
+    s->ctx_dirty = true;
+    return GD_OK;
+}
+
+extern "C" int gd_set_scaling(gd_system *s, double bi, double bt, double oi, double ot)
+{
+    if (!s) return fail(GD_EINVAL, "gd_set_scaling: NULL system");
+    if (!(bt > 0) || !(ot > 0) || !(bi > 0) || !(oi > 0)) return fail(GD_EINVAL, "gd_set_scaling: init and tau must be positive");
+    s->has_scaling = true; s->bs_init = bi; s->bs_tau = bt; s->bo_init = oi; s->bo_tau = ot;
+    for (auto &c : s->hctx) { c.bead_scale = bi; c.bond_scale = oi; }
+    s->ctx_dirty = true; s->list_valid = false;
+    return GD_OK;
+}
+
+extern "C" int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
+{
+    if (!s || !o) return fail(GD_EINVAL, "gd_get_context: NULL argument");
+    if (r >= s->R) return fail(GD_EINVAL, "gd_get_context: replica out of range");
+    memset(o, 0, sizeof *o);
+    const DevCtx &c = s->hctx[r];
+    o->step = c.step; o->time = c.time; o->bead_scale = c.bead_scale; o->bond_scale = c.bond_scale;
+    memcpy(o->semiaxes, c.semi, sizeof c.semi); memcpy(o->axial_reaction, c.react, sizeof c.react);
+    o->list_entries = s->lcount[r]; o->rebuilds = s->rebuilds; o->rollbacks = s->rollbacks;
+    o->rebuild_interval = s->K; o->list_radius = s->rv;
+    return GD_OK;
+}
+
+extern "C" int gd_begin_phase(gd_system *s, const double *semi)
+{
+    if (!s) return fail(GD_EINVAL, "gd_begin_phase: NULL system");
+    for (uint32_t r = 0; r < s->R; r++) {
+        DevCtx &c = s->hctx[r];
+        c.step = 0; c.time = 0; c.pending = 0;
+        if (s->has_scaling) { c.bead_scale = s->bs_init; c.bond_scale = s->bo_init; }
+        if (semi) memcpy(c.semi, semi + 3 * r, sizeof c.semi);
+    }
+    s->ctx_dirty = true; s->list_valid = false;
+    return GD_OK;
+}
+
+extern "C" int gd_set_context(gd_system *s, uint32_t r, int64_t step, double bead_scale, double bond_scale, const double semi[3])
+{
+    if (!s) return fail(GD_EINVAL, "gd_set_context: NULL system");
+    if (r >= s->R) return fail(GD_EINVAL, "gd_set_context: replica out of range");
+    if (!(bead_scale > 0) || !(bond_scale > 0)) return fail(GD_EINVAL, "gd_set_context: scales must be positive");
+    DevCtx &c = s->hctx[r];
+    c.step = step; c.bead_scale = bead_scale; c.bond_scale = bond_scale; c.pending = 0;
+    if (semi) memcpy(c.semi, semi, sizeof c.semi);
+    s->ctx_dirty = true; s->list_valid = false;
+    return GD_OK;
+}
+
+extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
+{
+    if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
+    if (t->skin > 0) s->skin = t->skin;
+    if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
+    s->adapt = t->adapt_interval;
+    if (t->list_width > 0 && t->list_width != s->W) { s->W = 0; s->nbr.resize(0); s->W = t->list_width; }
+    s->use_graph = t->use_graph;
+    s->list_valid = false;
+    return GD_OK;
+}
+extern "C" int gd_get_timing(gd_system *s, gd_timing *o) { if (!s || !o) return fail(GD_EINVAL, "gd_get_timing: NULL"); *o = s->timing; return GD_OK; }
+extern "C" int gd_get_stream(gd_system *s, void **st) { if (!s || !st) return fail(GD_EINVAL, "gd_get_stream: NULL"); *st = (void *)s->stream; return GD_OK; }
+
+// --------------------------------------------------------------- topology
+
+static float pair_cutoff(const gd_system *s)
+{
+    double m = 0;
+    if (s->has_pair) {
+        if (s->pair.eps_a != 0 && s->pair.sigma_a > m) m = s->pair.sigma_a;
+        if (s->pair.eps_b != 0 && s->pair.sigma_b > m) m = s->pair.sigma_b;
+    }
+    return (float)m;
+}
+
+// Flatten the host model into the bead-order device tables (bond adjacency in ELL form,
+// bending energies of the three triplets of each bead, point-source masks).
+static int finalize_topology(gd_system *s)
+{
+    if (!s->topo_dirty) return GD_OK;
+    HIPCHK(hipSetDevice(s->device));
+    const uint32_t N = s->N;
+    // bond types: static + dynamic sets
+    std::vector<gd_bond_params> types = s->btypes;
+    std::vector<int> terms = s->bterm;
+    std::vector<Bond> all = s->bonds;
+    for (int d = 0; d < 4; d++) if (s->dyn[d].used) {
+        if (types.size() >= GD_MAX_BOND_TYPES) return fail(GD_EINVAL, "too many bond parameter sets");
+        types.push_back(s->dyn[d].p); terms.push_back(GD_TERM_DYNAMIC);
+        const int t = (int)types.size() - 1;
+        for (size_t k = 0; k + 1 < s->dyn[d].pairs.size(); k += 2) all.push_back({s->dyn[d].pairs[k], s->dyn[d].pairs[k + 1], t});
+    }
+    std::vector<unsigned> deg(N, 0);
+    for (auto &b : all) { deg[b.i]++; deg[b.j]++; }
+    uint32_t WB = 0;
+    for (auto v : deg) WB = std::max(WB, v);
+    if (WB > 255) return fail(GD_EINVAL, "a bead has %u bonds (max 255)", WB);
+    std::vector<unsigned> adj((size_t)std::max(WB, 1u) * N, 0u);
+    std::vector<unsigned char> dg(N, 0);
+    for (auto &b : all) {
+        adj[(size_t)dg[b.i] * N + b.i] = b.j | ((unsigned)b.type << GD_ADJ_SHIFT); dg[b.i]++;
+        adj[(size_t)dg[b.j] * N + b.j] = b.i | ((unsigned)b.type << GD_ADJ_SHIFT); dg[b.j]++;
+    }
+    std::vector<BondType> bt(std::max<size_t>(types.size(), 1));
+    for (size_t i = 0; i < types.size(); i++) {
+        const gd_bond_params &p = types[i];
+        bt[i] = BondType{p.kind, p.mix, p.scale_by_bond_scale, p.p, p.q, p.minimum_image, terms[i],
+                         (float)p.k_a, (float)p.k_b, (float)p.l_a, (float)p.l_b};
+    }
+    // bending: energy of the triplet starting at each bead
+    std::vector<double> tE(N, 0.0);
+    for (auto &br : s->bends)
+        for (uint32_t i = br.start; i + 2 < br.end; i++) tE[i] += br.per_bead ? s->bend[i + 1] : br.energy;
+    std::vector<float4> bendE(N);
+    std::vector<int4> chain(N);
+    bool has_bend = false;
+    for (uint32_t j = 0; j < N; j++) {
+        const float el = j >= 2 ? (float)tE[j - 2] : 0.f, em = j >= 1 ? (float)tE[j - 1] : 0.f, ef = (float)tE[j];
+        bendE[j] = make_float4(el, em, ef, 0.f);
+        if (el != 0.f || em != 0.f || ef != 0.f) has_bend = true;
+        int4 c = make_int4(-1, -1, -1, -1);
+        if (el != 0.f) { c.x = (int)j - 2; c.y = (int)j - 1; }
+        if (em != 0.f) { c.y = (int)j - 1; c.z = (int)j + 1; }
+        if (ef != 0.f) { c.z = (int)j + 1; c.w = (int)j + 2; }
+        chain[j] = c;
+    }
+    std::vector<unsigned char> psm(N, 0);
+    for (size_t q = 0; q < s->psrc.size(); q++)
+        for (uint32_t i = 0; i < N; i++) if (s->psrc[q].mask.empty() || s->psrc[q].mask[i]) psm[i] |= (unsigned char)(1u << q);
+    std::vector<float2> ab(N);
+    std::vector<float> mob(N);
+    for (uint32_t i = 0; i < N; i++) { ab[i] = make_float2((float)s->a[i], (float)s->b[i]); mob[i] = (float)s->mob[i]; }
+
+    HIPCHK(s->ab_o.resize(N)); HIPCHK(s->mob_o.resize(N)); HIPCHK(s->bendE_o.resize(N)); HIPCHK(s->psmask_o.resize(N));
+    HIPCHK(s->bdeg_o.resize(N)); HIPCHK(s->badj_o.resize(adj.size())); HIPCHK(s->chain_o.resize(N)); HIPCHK(s->btab.resize(bt.size()));
+    HIPCHK(hipMemcpy(s->ab_o.p, ab.data(), N * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->mob_o.p, mob.data(), N * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->bendE_o.p, bendE.data(), N * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->psmask_o.p, psm.data(), N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->bdeg_o.p, dg.data(), N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->badj_o.p, adj.data(), adj.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->chain_o.p, chain.data(), N * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->btab.p, bt.data(), bt.size() * sizeof(BondType), hipMemcpyHostToDevice));
+    const size_t RNp = (size_t)s->R * s->Np;
+    if (WB != s->WB || !s->badj.p) { HIPCHK(s->badj.resize((size_t)std::max(WB, 1u) * RNp)); }
+    if (has_bend && !s->chain.p) HIPCHK(s->chain.resize(RNp));
+    s->WB = WB; s->has_bend = has_bend; s->has_bonds = !all.empty();
+    s->topo_dirty = false; s->list_valid = false;
+    return GD_OK;
+}
+
+// ------------------------------------------------------------ list builds
+
+static double scale_at(const gd_system *s, double init, double tau, double time) { (void)s; return 1.0 - (1.0 - init) * std::exp(-time / tau); }
+
+// bead_scale bound over the next `ahead` steps (monotone in time)
+static double bead_scale_bound(const gd_system *s, const gd_run_desc *run, uint32_t ahead)
+{
+    double m = 0;
+    for (auto &c : s->hctx) {
+        m = std::max(m, c.bead_scale);
+        if (run && (run->flags & GD_RUN_UPDATE_SCALES) && s->has_scaling)
+            m = std::max(m, scale_at(s, s->bs_init, s->bs_tau, (double)(c.step + ahead + 1) * run->timestep));
+    }
+    return m;
+}
+
+static void fill_common(gd_system *s, StepParams &p)
+{
+    memset(&p, 0, sizeof p);
+    p.N = s->N; p.Np = s->Np; p.R = s->R; p.nblk = s->nblk; p.stride = (size_t)s->R * s->Np;
+    p.periodic = s->box_kind == GD_BOX_PERIODIC;
+    for (int k = 0; k < 3; k++) { p.box[k] = (float)s->box[k]; p.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
+    p.pos_in = s->pos[s->pcur].p; p.pos_out = s->pos[s->pcur ^ 1].p; p.xb = s->xb.p; p.orig = s->orig[s->ocur].p;
+    p.ab = s->ab.p; p.mob = s->mobs.p; p.bendE = s->bendE.p; p.psmask = s->psmask.p;
+    p.nbr = s->nbr.p; p.ncnt = s->ncnt.p; p.W = s->W; p.badj = s->badj.p; p.bdeg = s->bdeg.p; p.chain = s->chain.p;
+    p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.react_part = s->react_part.p; p.flags = s->flags.p;
+    if (s->has_pair) {
+        const gd_pair_softcore &q = s->pair;
+        p.pair = PairP{(float)q.eps_a, (float)q.sigma_a, (float)q.eps_b, (float)q.sigma_b, q.p_a, q.q_a, q.p_b, q.q_b,
+                       q.mix, q.scale_by_bead_scale, pair_cutoff(s) > 0 ? 1 : 0, pair_cutoff(s)};
+    }
+    if (s->has_wall) {
+        const gd_wall &w = s->wall;
+        p.wall.eps_a = (float)w.eps_a; p.wall.sigma_a = (float)w.sigma_a; p.wall.eps_b = (float)w.eps_b; p.wall.sigma_b = (float)w.sigma_b;
+        p.wall.p_a = w.p_a; p.wall.q_a = w.q_a; p.wall.p_b = w.p_b; p.wall.q_b = w.q_b;
+        p.wall.wall_a = (float)w.wall_a_factor; p.wall.wall_b = (float)w.wall_b_factor; p.wall.scaled = w.scale_by_bead_scale;
+        p.wall.enabled = 1; p.wall.packing_spring = (float)w.packing_spring;
+        for (int k = 0; k < 3; k++) p.wall.spring[k] = w.semiaxes_spring[k];
+        p.wall.mobility = w.mobility;
+    }
+    p.scaling = ScaleP{s->has_scaling ? 1 : 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau};
+    p.btab = s->btab.p; p.nbt = (int)(s->btab.n);
+    p.nps = (int)s->psrc.size();
+    for (int q = 0; q < p.nps; q++) {
+        p.ps[q].kind = s->psrc[q].kind; p.ps[q].k = (float)s->psrc[q].k; p.ps[q].b = (float)s->psrc[q].b;
+        for (int k = 0; k < 3; k++) p.ps[q].p[k] = (float)s->psrc[q].p[k];
+    }
+    p.has_bend = s->has_bend; p.has_bonds = s->has_bonds;
+    p.rv = s->rv; p.term_mask = GD_TERM_ALL;
+    p.fout = s->fout.p; p.epart = s->epart.p;
+}
+
+// Enqueue one list build (counting sort into slot order + ELL fill) with radius rv.
+static int enqueue_build(gd_system *s, float rv, bool with_list)
+{
+    if (with_list && (s->W == 0 || !s->nbr.p)) {
+        if (s->W == 0) s->W = 32;
+        HIPCHK(s->nbr.resize((size_t)s->W * s->R * s->Np, false));
+    }
+    BuildParams b;
+    memset(&b, 0, sizeof b);
+    b.N = s->N; b.Np = s->Np; b.R = s->R; b.nblk = s->nblk; b.stride = (size_t)s->R * s->Np;
+    b.periodic = s->box_kind == GD_BOX_PERIODIC;
+    for (int k = 0; k < 3; k++) { b.box[k] = (float)s->box[k]; b.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
+    b.rv = rv; b.ncell_cap = s->ncell_cap;
+    b.pos_in = s->pos[s->pcur].p; b.pos_out = s->pos[s->pcur ^ 1].p; b.xb = s->xb.p;
+    b.orig_in = s->orig[s->ocur].p; b.orig_out = s->orig[s->ocur ^ 1].p; b.slot_of = s->slot_of.p;
+    b.cell_id = s->cell_id.p; b.rank = s->rank.p; b.cell_cnt = s->cell_cnt.p; b.cell_start = s->cell_start.p;
+    b.bbox = s->bbox.p; b.grid = s->grid.p;
+    b.ab_o = s->ab_o.p; b.mob_o = s->mob_o.p; b.bendE_o = s->bendE_o.p; b.psmask_o = s->psmask_o.p;
+    b.badj_o = s->badj_o.p; b.bdeg_o = s->bdeg_o.p; b.chain_o = s->has_bend ? s->chain_o.p : nullptr; b.WB = s->WB;
+    b.ab = s->ab.p; b.mob = s->mobs.p; b.bendE = s->bendE.p; b.psmask = s->psmask.p; b.badj = s->badj.p; b.bdeg = s->bdeg.p;
+    b.chain = s->chain.p; b.nbr = with_list ? s->nbr.p : nullptr; b.ncnt = s->ncnt.p; b.W = s->W;
+    b.flags = s->flags.p; b.lcount = s->lcount_d.p;
+    gd_launch_build(b, s->stream);
+    s->pcur ^= 1; s->ocur ^= 1;
+    s->rv = rv; s->steps_since_build = 0; s->rebuilds++;
+    s->timing.rebuild_launches++;
+    return GD_OK;
+}
+
+static int read_flags(gd_system *s, std::vector<unsigned> &f)
+{
+    f.resize((size_t)s->R * GD_NFLAGS);
+    HIPCHK(hipMemcpyAsync(f.data(), s->flags.p, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return GD_OK;
+}
+static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (size_t)s->R * GD_NFLAGS * sizeof(unsigned), s->stream)); return GD_OK; }
+
+// Synchronous build used outside gd_run: grows the list width until nothing overflows.
+static int build_now(gd_system *s, float rv, bool with_list)
+{
+    for (int attempt = 0; attempt < 8; attempt++) {
+        GDCHK(clear_flags(s));
+        GDCHK(enqueue_build(s, rv, with_list));
+        std::vector<unsigned> f;
+        GDCHK(read_flags(s, f));
+        unsigned need = 0; bool over = false;
+        for (uint32_t r = 0; r < s->R; r++) { over |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] != 0; need = std::max(need, f[r * GD_NFLAGS + GD_FLAG_NEED_W]); }
+        if (!over) {
+            HIPCHK(hipMemcpy(s->lcount.data(), s->lcount_d.p, s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            GDCHK(clear_flags(s));
+            return GD_OK;
+        }
+        s->W = std::max(need + need / 4 + 4, s->W * 2);
+        HIPCHK(s->nbr.resize((size_t)s->W * s->R * s->Np, false));
+    }
+    return fail(GD_ENOMEM, "neighbour list width did not converge (W=%u)", s->W);
+}
+
+static int prepare(gd_system *s)
+{
+    HIPCHK(hipSetDevice(s->device));
+    GDCHK(finalize_topology(s));
+    GDCHK(upload_ctx(s));
+    return GD_OK;
+}
+
+static float list_radius(gd_system *s, const gd_run_desc *run, uint32_t ahead)
+{
+    const float cut = pair_cutoff(s);
+    if (!(cut > 0)) return 1.0f;
+    const double sc = s->pair.scale_by_bead_scale ? bead_scale_bound(s, run, ahead) : 1.0;
+    return (float)(cut * sc * (1.0 + s->skin));
+}
+
+static int ensure_fresh_list(gd_system *s)
+{
+    if (s->list_valid && s->steps_since_build == 0) return GD_OK;
+    GDCHK(build_now(s, list_radius(s, nullptr, 0), pair_cutoff(s) > 0));
+    s->list_valid = true;
+    return GD_OK;
+}
+
+// ---------------------------------------------------------------- stepping
+
+static hipEvent_t get_event(gd_system *s, size_t i)
+{
+    while (s->events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; s->events.push_back(e); }
+    return s->events[i];
+}
+
+extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
+{
+    if (!s || !run) return fail(GD_EINVAL, "gd_run: NULL argument");
+    if (run->spacestep != 0) return fail(GD_EUNSUPPORTED, "gd_run: spacestep != 0 (adaptive timestep) is not supported");
+    if (run->steps < 0 || !(run->timestep > 0) || run->temperature < 0) return fail(GD_EINVAL, "gd_run: bad steps/timestep/temperature");
+    if (run->noise_mode < 0 || run->noise_mode > GD_NOISE_HOST)
+        return fail(run->noise_mode == 3 ? GD_EUNSUPPORTED : GD_EINVAL, "gd_run: noise_mode %d not available on the device", run->noise_mode);
+    if (run->noise_mode == GD_NOISE_HOST && !run->host_noise) return fail(GD_EINVAL, "gd_run: host noise requested without array");
+    if ((run->flags & GD_RUN_WALL_DYNAMICS) && !s->has_wall) return fail(GD_ESTATE, "gd_run: wall dynamics requested without a wall");
+    if ((run->flags & GD_RUN_UPDATE_SCALES) && !s->has_scaling) return fail(GD_ESTATE, "gd_run: scale updates requested without gd_set_scaling");
+    GDCHK(prepare(s));
+    const bool with_list = pair_cutoff(s) > 0;
+    const size_t RN = (size_t)s->R * s->N;
+    memset(&s->timing, 0, sizeof s->timing);
+
+    // injected noise lives on the device as float (R,N,3) per step
+    const bool host_noise = run->noise_mode == GD_NOISE_HOST && run->temperature > 0;
+    if (host_noise) {
+        const size_t n = (size_t)run->steps * RN * 3;
+        std::vector<float> h(n);
+        for (size_t i = 0; i < n; i++) h[i] = (float)run->host_noise[i];
+        HIPCHK(s->noise.resize(n, false));
+        HIPCHK(hipMemcpy(s->noise.p, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    int64_t done = 0;
+    while (done < run->steps) {
+        // ---- one verified chunk
+        const int64_t chunk = std::min<int64_t>(run->steps - done, std::max<int64_t>(256, 32ll * s->K));
+        // snapshot for rollback: positions in bead order + context
+        gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->snap.p, s->N, s->Np, s->R, 0, s->stream);
+        const std::vector<DevCtx> snap_ctx = s->hctx;
+        GDCHK(clear_flags(s));
+
+        StepParams p;
+        size_t nev = 0;
+        float step_ms = 0, build_ms = 0;
+        std::vector<std::pair<size_t, int>> spans;   // event index, kind (0 step, 1 build)
+        hipEvent_t ev_begin = get_event(s, nev++);
+        HIPCHK(hipEventRecord(ev_begin, s->stream));
+        int64_t k = 0;
+        uint64_t visited = 0;
+        while (k < chunk) {
+            if (!s->list_valid || s->steps_since_build >= s->K) {
+                hipEvent_t e0 = get_event(s, nev++), e1 = get_event(s, nev++);
+                HIPCHK(hipEventRecord(e0, s->stream));
+                GDCHK(enqueue_build(s, list_radius(s, run, (uint32_t)(k + s->K)), with_list));
+                HIPCHK(hipEventRecord(e1, s->stream));
+                spans.push_back({nev - 2, 1});
+                s->list_valid = true;
+            }
+            const int64_t n = std::min<int64_t>((int64_t)s->K - s->steps_since_build, chunk - k);
+            hipEvent_t e0 = get_event(s, nev++), e1 = get_event(s, nev++);
+            HIPCHK(hipEventRecord(e0, s->stream));
+            for (int64_t q = 0; q < n; q++) {
+                fill_common(s, p);
+                p.dt_d = run->timestep; p.dt = (float)run->timestep; p.kT = (float)run->temperature; p.seed = run->seed;
+                p.noise_mode = run->noise_mode; p.run_flags = run->flags;
+                p.host_noise = host_noise ? s->noise.p + (size_t)(done + k + q) * RN * 3 : nullptr;
+                p.record_disp = (q == n - 1);
+                gd_launch_step(p, GD_MODE_STEP, s->stream);
+                s->pcur ^= 1; s->ccur ^= 1;
+            }
+            HIPCHK(hipEventRecord(e1, s->stream));
+            spans.push_back({nev - 2, 0});
+            s->timing.step_launches += (uint64_t)n;
+            s->steps_since_build += (uint32_t)n;
+            k += n;
+            (void)visited;
+        }
+        // apply the callback of the last step, then check the chunk
+        fill_common(s, p);
+        p.dt_d = run->timestep; p.dt = (float)run->timestep; p.run_flags = run->flags;
+        gd_launch_finalize(p, 0, s->stream);
+        s->ccur ^= 1;
+        hipEvent_t ev_end = get_event(s, nev++);
+        HIPCHK(hipEventRecord(ev_end, s->stream));
+        std::vector<unsigned> f;
+        GDCHK(read_flags(s, f));
+        bool violated = false, over = false; unsigned need = 0; float maxd2 = 0;
+        for (uint32_t r = 0; r < s->R; r++) {
+            violated |= f[r * GD_NFLAGS + GD_FLAG_VIOLATION] != 0;
+            over |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] != 0;
+            need = std::max(need, f[r * GD_NFLAGS + GD_FLAG_NEED_W]);
+            float d2; memcpy(&d2, &f[r * GD_NFLAGS + GD_FLAG_MAXDISP2], 4); maxd2 = std::max(maxd2, d2);
+        }
+        if (violated || over) {
+            // roll the chunk back: restore bead-order positions + context, shorten the interval / widen the list
+            s->rollbacks++;
+            HIPCHK(hipMemcpy2DAsync(s->pos[s->pcur].p, (size_t)s->Np * sizeof(float4), s->snap.p, (size_t)s->N * sizeof(float4),
+                                    (size_t)s->N * sizeof(float4), s->R, hipMemcpyDeviceToDevice, s->stream));
+            gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
+            s->hctx = snap_ctx; s->ctx_dirty = true;
+            GDCHK(upload_ctx(s));
+            s->list_valid = false;
+            if (over) { s->W = std::max(need + need / 4 + 4, s->W * 2); HIPCHK(s->nbr.resize((size_t)s->W * s->R * s->Np, false)); }
+            if (violated) {
+                if (s->K == 1) {
+                    if (s->skin > 8) return fail(GD_ESTATE, "gd_run: Verlet skin cannot cover one step (timestep too large?)");
+                    s->skin *= 1.5;
+                } else s->K = std::max(1u, s->K / 2);
+            }
+            s->timing.step_launches -= std::min<uint64_t>(s->timing.step_launches, (uint64_t)chunk);
+            continue;
+        }
+        // accepted: timing, context mirror, cadence adaptation
+        float ms = 0;
+        for (auto &sp : spans) {
+            HIPCHK(hipEventElapsedTime(&ms, s->events[sp.first], s->events[sp.first + 1]));
+            (sp.second ? build_ms : step_ms) += ms;
+        }
+        HIPCHK(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        s->timing.total_ms += ms; s->timing.step_kernel_ms += step_ms; s->timing.rebuild_ms += build_ms;
+        GDCHK(download_ctx(s));
+        HIPCHK(hipMemcpy(s->lcount.data(), s->lcount_d.p, s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long L = 0;
+        for (auto v : s->lcount) L += v;
+        s->timing.list_entries_visited += L * (uint64_t)chunk;   // L of the last build, per step
+        if (s->adapt && with_list) {
+            const double cut_now = pair_cutoff(s) * (s->pair.scale_by_bead_scale ? bead_scale_bound(s, nullptr, 0) : 1.0);
+            const double lim = 0.5 * (s->rv - cut_now), d = std::sqrt((double)maxd2);
+            if (lim > 0 && d > 0) {
+                // displacement grows ~ sqrt(steps): aim at 60% of the skin at the end of an interval
+                const double ratio = d / lim;
+                double knew = (double)s->K * (0.6 / ratio) * (0.6 / ratio);
+                knew = std::min(knew, 2.0 * s->K + 1);
+                s->K = (uint32_t)std::max(1.0, std::min(200.0, std::floor(knew)));
+            } else if (d == 0) s->K = std::min(200u, s->K * 2);
+        }
+        done += chunk;
+    }
+    return GD_OK;
+}
+
+// ------------------------------------------------------------- observation
+
+extern "C" int gd_compute_energy(gd_system *s, uint32_t mask, double *energy)
+{
+    if (!s || !energy) return fail(GD_EINVAL, "gd_compute_energy: NULL argument");
+    GDCHK(prepare(s));
+    GDCHK(ensure_fresh_list(s));
+    StepParams p;
+    fill_common(s, p);
+    p.term_mask = mask;
+    gd_launch_step(p, GD_MODE_ENERGY, s->stream);
+    std::vector<double> part((size_t)s->R * s->nblk);
+    HIPCHK(hipMemcpyAsync(part.data(), s->epart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (uint32_t r = 0; r < s->R; r++) {
+        double e = 0;
+        for (uint32_t b = 0; b < s->nblk; b++) e += part[(size_t)r * s->nblk + b];
+        energy[r] = e;
+    }
+    return GD_OK;
+}
+
+extern "C" int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
+{
+    if (!s || !forces) return fail(GD_EINVAL, "gd_compute_forces: NULL argument");
+    GDCHK(prepare(s));
+    GDCHK(ensure_fresh_list(s));
+    StepParams p;
+    fill_common(s, p);
+    p.term_mask = mask;
+    HIPCHK(hipMemsetAsync(s->react_part.p, 0, s->react_part.n * sizeof(float4), s->stream));
+    gd_launch_step(p, GD_MODE_FORCE, s->stream);
+    if (s->has_wall) { gd_launch_finalize(p, 1, s->stream); s->ccur ^= 1; }
+    const size_t RN = (size_t)s->R * s->N;
+    std::vector<float4> h(RN);
+    HIPCHK(hipMemcpyAsync(h.data(), s->fout.p, RN * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (size_t i = 0; i < RN; i++) { forces[3 * i] = h[i].x; forces[3 * i + 1] = h[i].y; forces[3 * i + 2] = h[i].z; }
+    if (s->has_wall) GDCHK(download_ctx(s));
+    return GD_OK;
+}
+
+extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *pairs, uint64_t cap, uint64_t *n_pairs)
+{
+    if (!s || !n_pairs || (cap && !pairs)) return fail(GD_EINVAL, "gd_search_pairs: NULL argument");
+    if (r >= s->R || !(dcut > 0)) return fail(GD_EINVAL, "gd_search_pairs: bad replica or cutoff");
+    GDCHK(prepare(s));
+    GDCHK(build_now(s, (float)dcut, true));
+    s->list_valid = false;   // the force list was overwritten with the search radius
+    const uint32_t N = s->N, W = s->W;
+    std::vector<unsigned> cnt(N), org(N), nb((size_t)W * N);
+    HIPCHK(hipMemcpy(cnt.data(), s->ncnt.p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(org.data(), s->orig[s->ocur].p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(nb.data(), (size_t)N * sizeof(unsigned), s->nbr.p + (size_t)r * s->Np, (size_t)s->R * s->Np * sizeof(unsigned),
+                       (size_t)N * sizeof(unsigned), W, hipMemcpyDeviceToHost));
+    uint64_t n = 0;
+    for (uint32_t sl = 0; sl < N; sl++)
+        for (uint32_t k = 0; k < cnt[sl]; k++) {
+            const uint32_t i = org[sl], j = org[nb[(size_t)k * N + sl]];
+            if (i < j) { if (n < cap) { pairs[2 * n] = i; pairs[2 * n + 1] = j; } n++; }
+        }
+    *n_pairs = n;
+    return GD_OK;
+}

@@ -1,0 +1,745 @@
+// gdyn_kernels.hip -- hand-written HIP kernels (gfx950, wave64) of the Brownian-dynamics path.
+//
+//   k_step<MODE,PERIODIC>  one thread per bead slot: neighbour-list pair forces (AB-mixed
+//                          soft cores), bonded / bending / point-source / ellipsoid-wall forces,
+//                          Euler-Maruyama update with Philox4x32-10 noise, Verlet-skin check,
+//                          per-block wall-reaction partials.  The per-step "callback" state
+//                          (time, bead/bond scale, wall semiaxes ODE; reference
+//                          5-sim-genome/src/simulation_interphase/simulation_driver_interphase.cc:12-80)
+//                          is advanced by wave 0 of every block in the prologue of the NEXT
+//                          launch, so a run of steps needs no host round trip.
+//   k_bbox .. k_fill       neighbour search (micromd md::neighbor_searcher; call sites e.g.
+//                          simulation_interphase/contact_map.cc:64-66): bounding box, cell
+//                          binning, counting sort into slot order, ELL Verlet list fill.
+//
+// MFMA is not used: the path is an irregular short-range N-body sum.
+#include "gdyn_types.h"
+
+#define TERM_PAIR 1u
+#define TERM_BOND 2u
+#define TERM_BEND 4u
+#define TERM_POINT 8u
+#define TERM_WALL 16u
+#define TERM_DYNAMIC 32u
+#define RUN_UPDATE_SCALES 1
+#define RUN_WALL_DYNAMICS 2
+#define NOISE_PHILOX 0
+#define NOISE_ZERO 1
+#define NOISE_HOST 2
+#define POT_HARMONIC 0
+#define POT_SPRING 1
+#define POT_SEMISPRING 2
+#define POT_SOFTCORE 3
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// u2^(n/2) for even n in {0,2,4,6,10}
+__device__ __forceinline__ float pow_half(float u2, int n)
+{
+    const float u4 = u2 * u2;
+    switch (n) {
+    case 0: return 1.0f;
+    case 2: return u2;
+    case 4: return u4;
+    case 6: return u4 * u2;
+    default: return u4 * u4 * u2;   // 10
+    }
+}
+__device__ __forceinline__ float pow_q(float g, int q)   // g^q, q in 0..3
+{
+    switch (q) {
+    case 0: return 1.0f;
+    case 1: return g;
+    case 2: return g * g;
+    default: return g * g * g;
+    }
+}
+
+// md::softcore_potential<P,Q>: U = eps (1-(r/sigma)^P)^Q for r<sigma.
+// Returns fr with F_on_i = fr * (x_i - x_j); energy in e.
+__device__ __forceinline__ void softcore(float eps, float inv_s2, int P, int Q, float r2, float &e, float &fr)
+{
+    const float u2 = r2 * inv_s2;
+    e = 0.0f; fr = 0.0f;
+    if (u2 < 1.0f && eps != 0.0f) {
+        const float upm2 = pow_half(u2, P - 2);
+        const float g = 1.0f - upm2 * u2;
+        const float gq1 = pow_q(g, Q - 1);
+        e = eps * gq1 * g;
+        fr = eps * (float)(P * Q) * inv_s2 * gq1 * upm2;
+    }
+}
+
+__device__ __forceinline__ void bond_pot(int kind, float K, float l, int P, int Q, float r2, float &e, float &fr)
+{
+    e = 0.0f; fr = 0.0f;
+    if (kind == POT_HARMONIC) {
+        e = 0.5f * K * r2; fr = -K;
+    } else if (kind == POT_SOFTCORE) {
+        softcore(K, 1.0f / (l * l), P, Q, r2, e, fr);
+    } else {
+        const float d = sqrtf(r2);
+        const float x = d - l;
+        if (d > 0.0f && (kind == POT_SPRING || x > 0.0f)) { e = 0.5f * K * x * x; fr = -K * x / d; }
+    }
+}
+
+__device__ __forceinline__ float3 min_image(float3 d, const float *box, const float *inv_box)
+{
+    d.x -= box[0] * rintf(d.x * inv_box[0]);
+    d.y -= box[1] * rintf(d.y * inv_box[1]);
+    d.z -= box[2] * rintf(d.z * inv_box[2]);
+    return d;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11); counter = (bead, step_lo, step_hi, replica), key = seed.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned &o0, unsigned &o1, unsigned &o2, unsigned &o3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+
+__device__ __forceinline__ float3 philox_normal3(unsigned long long seed, unsigned bead, long long step, unsigned replica)
+{
+    unsigned o0, o1, o2, o3;
+    philox4x32_10(bead, (unsigned)((unsigned long long)step & 0xffffffffull), (unsigned)((unsigned long long)step >> 32), replica,
+                  (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), o0, o1, o2, o3);
+    // Box-Muller; v_sin/v_cos take their argument in revolutions
+    const float r0 = sqrtf(-2.0f * __logf(u01(o0))), r1 = sqrtf(-2.0f * __logf(u01(o2)));
+    const float t0 = u01(o1), t1 = u01(o3);
+    return make_float3(r0 * __builtin_amdgcn_cosf(t0), r0 * __builtin_amdgcn_sinf(t0), r1 * __builtin_amdgcn_cosf(t1));
+}
+
+// cosine bending: U = e (1 - cos theta), d1 = x_j - x_i, d2 = x_k - x_j. Forces on the end beads.
+__device__ __forceinline__ bool bend_forces(float3 d1, float3 d2, float e, float3 &fi, float3 &fk, float &cs)
+{
+    const float n1 = d1.x * d1.x + d1.y * d1.y + d1.z * d1.z, n2 = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
+    if (n1 == 0.0f || n2 == 0.0f) return false;
+    const float il1 = rsqrtf(n1), il2 = rsqrtf(n2);
+    cs = (d1.x * d2.x + d1.y * d2.y + d1.z * d2.z) * il1 * il2;
+    const float a1 = e * il1, a2 = e * il2;
+    fi = make_float3(-a1 * (d2.x * il2 - cs * d1.x * il1), -a1 * (d2.y * il2 - cs * d1.y * il1), -a1 * (d2.z * il2 - cs * d1.z * il1));
+    fk = make_float3(a2 * (d1.x * il1 - cs * d2.x * il2), a2 * (d1.y * il1 - cs * d2.y * il2), a2 * (d1.z * il1 - cs * d2.z * il2));
+    return true;
+}
+
+// The per-step callback state of the drivers, advanced on the device
+// (simulation_driver_interphase.cc:14,42-43,59-80). Wave-cooperative: all 64 lanes call it.
+__device__ __forceinline__ void apply_callback(DevCtx &c, const StepParams &p, unsigned r, int lane)
+{
+    double rx = 0, ry = 0, rz = 0;
+    if (p.wall.enabled) {
+        for (unsigned b = lane; b < p.nblk; b += 64) {
+            const float4 v = p.react_part[(size_t)r * p.nblk + b];
+            rx += v.x; ry += v.y; rz += v.z;
+        }
+        rx = wave_sum_d(rx); ry = wave_sum_d(ry); rz = wave_sum_d(rz);
+    }
+    c.step += 1;
+    c.time = (double)c.step * p.dt_d;
+    if ((p.run_flags & RUN_UPDATE_SCALES) && p.scaling.enabled) {
+        c.bead_scale = 1.0 - (1.0 - p.scaling.bead_init) * exp(-c.time / p.scaling.bead_tau);
+        c.bond_scale = 1.0 - (1.0 - p.scaling.bond_init) * exp(-c.time / p.scaling.bond_tau);
+    }
+    c.react[0] = rx; c.react[1] = ry; c.react[2] = rz;
+    if ((p.run_flags & RUN_WALL_DYNAMICS) && p.wall.enabled) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) c.semi[k] += p.dt_d * p.wall.mobility * (c.react[k] - p.wall.spring[k] * c.semi[k]);
+    }
+    c.pending = 0;
+}
+
+struct CtxF {
+    float bead_scale, bond_scale, semi[3];
+    long long step;
+};
+
+// ------------------------------------------------------------------- k_step
+
+template <int MODE, bool PERIODIC>
+__global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
+{
+    __shared__ BondType s_bt[GD_MAX_BOND_TYPES];
+    __shared__ CtxF s_ctx;
+    __shared__ float s_red[GD_BLOCK / 64][4];
+    __shared__ double s_e[GD_BLOCK / 64];
+
+    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
+    if (wid == 0) {
+        DevCtx c = p.ctx_in[r];
+        if (MODE == GD_MODE_STEP) {
+            if (c.pending) apply_callback(c, p, r, lane);
+            if (lane == 0) {
+                s_ctx.bead_scale = (float)c.bead_scale; s_ctx.bond_scale = (float)c.bond_scale;
+                s_ctx.semi[0] = (float)c.semi[0]; s_ctx.semi[1] = (float)c.semi[1]; s_ctx.semi[2] = (float)c.semi[2];
+                s_ctx.step = c.step;
+                if (blk == 0) { c.pending = 1; p.ctx_out[r] = c; }
+            }
+        } else if (lane == 0) {
+            s_ctx.bead_scale = (float)c.bead_scale; s_ctx.bond_scale = (float)c.bond_scale;
+            s_ctx.semi[0] = (float)c.semi[0]; s_ctx.semi[1] = (float)c.semi[1]; s_ctx.semi[2] = (float)c.semi[2];
+            s_ctx.step = c.step;
+        }
+    }
+    __syncthreads();
+
+    const unsigned slot = blk * GD_BLOCK + tid;
+    const bool valid = slot < p.N;
+    const size_t rbase = (size_t)r * p.Np;
+    const size_t g = rbase + slot;
+    const unsigned mask = (MODE == GD_MODE_STEP) ? 63u : p.term_mask;
+
+    float3 F = make_float3(0.f, 0.f, 0.f);
+    float3 react = make_float3(0.f, 0.f, 0.f);
+    float E = 0.f;
+    float disp2 = 0.f;
+
+    if (valid) {
+        const float4 xi4 = p.pos_in[g];
+        const float3 xi = make_float3(xi4.x, xi4.y, xi4.z);
+        const float4 *__restrict__ rpos = p.pos_in + rbase;
+        const float2 *__restrict__ rab = p.ab + rbase;
+        const float2 abi = p.ab[g];
+
+        // ---- non-bonded pairs over the Verlet list (a3, a5)
+        if (p.pair.enabled && (mask & TERM_PAIR)) {
+            const float sc = p.pair.scaled ? s_ctx.bead_scale : 1.0f;
+            const float sa = p.pair.sigma_a * sc, sb = p.pair.sigma_b * sc;
+            const float inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f, inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
+            const float cut = p.pair.cutoff * sc, cut2 = cut * cut;
+            const unsigned cnt = p.ncnt[g];
+            const unsigned *__restrict__ col = p.nbr + g;
+            for (unsigned k = 0; k < cnt; k++) {
+                const unsigned j = col[(size_t)k * p.stride];
+                const float4 xj = rpos[j];
+                float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+                if (PERIODIC) d = min_image(d, p.box, p.inv_box);
+                const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                if (r2 < cut2) {
+                    float wa = 1.0f, wb = 1.0f;
+                    if (p.pair.mix) { const float2 abj = rab[j]; wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y); }
+                    float ea, fa, eb, fb;
+                    softcore(p.pair.eps_a, inv_sa2, p.pair.p_a, p.pair.q_a, r2, ea, fa);
+                    softcore(p.pair.eps_b, inv_sb2, p.pair.p_b, p.pair.q_b, r2, eb, fb);
+                    const float f = wa * fa + wb * fb;
+                    F.x += f * d.x; F.y += f * d.y; F.z += f * d.z;
+                    if (MODE == GD_MODE_ENERGY) E += 0.5f * (wa * ea + wb * eb);
+                }
+            }
+            if (MODE == GD_MODE_STEP) {
+                // Verlet-skin check: the list is complete for this force evaluation iff every
+                // bead moved less than (rv - cutoff)/2 since the build.
+                const float4 x0 = p.xb[g];
+                const float dx = xi.x - x0.x, dy = xi.y - x0.y, dz = xi.z - x0.z;
+                disp2 = dx * dx + dy * dy + dz * dz;
+                const float lim = 0.5f * (p.rv - cut);
+                if (!(lim > 0.f) || disp2 > lim * lim) p.flags[r * GD_NFLAGS + GD_FLAG_VIOLATION] = 1u;
+            }
+        }
+
+        // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
+        if (p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
+            const unsigned deg = p.bdeg[g];
+            const unsigned *__restrict__ col = p.badj + g;
+            for (unsigned k = 0; k < deg; k++) {
+                const unsigned ent = col[(size_t)k * p.stride];
+                const unsigned j = ent & GD_ADJ_MASK;
+                const BondType bt = s_bt[ent >> GD_ADJ_SHIFT];
+                if (!(mask & (unsigned)bt.term)) continue;
+                const float4 xj = rpos[j];
+                float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+                if (PERIODIC && bt.minimg) d = min_image(d, p.box, p.inv_box);
+                const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                float K = bt.ka, l = bt.la;
+                if (bt.mix) {
+                    const float2 abj = rab[j];
+                    const float a = 0.5f * (abi.x + abj.x), b = 0.5f * (abi.y + abj.y);
+                    K = a * bt.ka + b * bt.kb; l = a * bt.la + b * bt.lb;
+                }
+                if (bt.scaled) { const float s = s_ctx.bond_scale; K = K * (1.0f / (s * s)); l = l * s; }
+                float e, fr;
+                bond_pot(bt.kind, K, l, bt.p, bt.q, r2, e, fr);
+                F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
+                if (MODE == GD_MODE_ENERGY) E += 0.5f * e;
+            }
+        }
+
+        // ---- cosine bending over the (up to) three triplets this bead belongs to (a7)
+        if (p.has_bend && (mask & TERM_BEND)) {
+            const float4 be = p.bendE[g];
+            if (be.x != 0.f || be.y != 0.f || be.z != 0.f) {
+                const int4 c4 = p.chain[g];
+                float3 xm2 = xi, xm1 = xi, xp1 = xi, xp2 = xi;
+                if (c4.x >= 0) { const float4 t = rpos[c4.x]; xm2 = make_float3(t.x, t.y, t.z); }
+                if (c4.y >= 0) { const float4 t = rpos[c4.y]; xm1 = make_float3(t.x, t.y, t.z); }
+                if (c4.z >= 0) { const float4 t = rpos[c4.z]; xp1 = make_float3(t.x, t.y, t.z); }
+                if (c4.w >= 0) { const float4 t = rpos[c4.w]; xp2 = make_float3(t.x, t.y, t.z); }
+                float3 fi, fk; float cs;
+                if (be.x != 0.f) {   // (i-2, i-1, i): this bead is the last one
+                    const float3 d1 = make_float3(xm1.x - xm2.x, xm1.y - xm2.y, xm1.z - xm2.z);
+                    const float3 d2 = make_float3(xi.x - xm1.x, xi.y - xm1.y, xi.z - xm1.z);
+                    if (bend_forces(d1, d2, be.x, fi, fk, cs)) { F.x += fk.x; F.y += fk.y; F.z += fk.z; }
+                }
+                if (be.y != 0.f) {   // (i-1, i, i+1): middle
+                    const float3 d1 = make_float3(xi.x - xm1.x, xi.y - xm1.y, xi.z - xm1.z);
+                    const float3 d2 = make_float3(xp1.x - xi.x, xp1.y - xi.y, xp1.z - xi.z);
+                    if (bend_forces(d1, d2, be.y, fi, fk, cs)) {
+                        F.x -= fi.x + fk.x; F.y -= fi.y + fk.y; F.z -= fi.z + fk.z;
+                        if (MODE == GD_MODE_ENERGY) E += be.y * (1.0f - cs);
+                    }
+                }
+                if (be.z != 0.f) {   // (i, i+1, i+2): first
+                    const float3 d1 = make_float3(xp1.x - xi.x, xp1.y - xi.y, xp1.z - xi.z);
+                    const float3 d2 = make_float3(xp2.x - xp1.x, xp2.y - xp1.y, xp2.z - xp1.z);
+                    if (bend_forces(d1, d2, be.z, fi, fk, cs)) { F.x += fi.x; F.y += fi.y; F.z += fi.z; }
+                }
+            }
+        }
+
+        // ---- point sources (a8)
+        if (p.nps > 0 && (mask & TERM_POINT)) {
+            const unsigned pm = p.psmask[g];
+            for (int s = 0; s < p.nps; s++) {
+                if (!((pm >> s) & 1u)) continue;
+                const float3 d = make_float3(xi.x - p.ps[s].p[0], xi.y - p.ps[s].p[1], xi.z - p.ps[s].p[2]);
+                const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                float e, fr;
+                bond_pot(p.ps[s].kind, p.ps[s].k, p.ps[s].b, 2, 1, r2, e, fr);
+                F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
+                if (MODE == GD_MODE_ENERGY) E += e;
+            }
+        }
+
+        // ---- ellipsoid wall (a9): second-order nearest-surface construction
+        // (5-sim-genome/src/analyze_lamina/geometry.py:13-28), conjugate form u = C/(B+sqrt(B^2-AC)).
+        if (p.wall.enabled && (mask & TERM_WALL)) {
+            const float ia = 1.0f / (s_ctx.semi[0] * s_ctx.semi[0]), ib = 1.0f / (s_ctx.semi[1] * s_ctx.semi[1]),
+                        ic = 1.0f / (s_ctx.semi[2] * s_ctx.semi[2]);
+            const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);
+            const float C = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z - 1.0f;
+            const float B = s1.x * s1.x + s1.y * s1.y + s1.z * s1.z;
+            const float A = s1.x * s1.x * ia + s1.y * s1.y * ib + s1.z * s1.z * ic;
+            const float den = B + sqrtf(fmaxf(B * B - A * C, 0.f));
+            if (den > 0.f && C != 0.f) {
+                const float u = C / den;
+                const float3 dl = make_float3(u * s1.x, u * s1.y, u * s1.z);
+                const float r2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z;
+                float e = 0.f, fr = 0.f;
+                if (C < 0.f) {
+                    const float sc = p.wall.scaled ? s_ctx.bead_scale : 1.0f;
+                    const float sa = 0.5f * p.wall.sigma_a * sc, sb = 0.5f * p.wall.sigma_b * sc;
+                    const float wa = 0.5f * (abi.x + p.wall.wall_a), wb = 0.5f * (abi.y + p.wall.wall_b);
+                    float ea, fa, eb, fb;
+                    softcore(p.wall.eps_a, sa > 0.f ? 1.0f / (sa * sa) : 0.f, p.wall.p_a, p.wall.q_a, r2, ea, fa);
+                    softcore(p.wall.eps_b, sb > 0.f ? 1.0f / (sb * sb) : 0.f, p.wall.p_b, p.wall.q_b, r2, eb, fb);
+                    e = wa * ea + wb * eb; fr = wa * fa + wb * fb;
+                } else {
+                    e = 0.5f * p.wall.packing_spring * r2; fr = -p.wall.packing_spring;
+                }
+                if (fr != 0.f) {
+                    const float3 fw = make_float3(fr * dl.x, fr * dl.y, fr * dl.z);
+                    F.x += fw.x; F.y += fw.y; F.z += fw.z;
+                    // axial_reaction_k = -F_k q_k / a_k, q = contact point on the surface
+                    react.x = -fw.x * (xi.x - dl.x) / s_ctx.semi[0];
+                    react.y = -fw.y * (xi.y - dl.y) / s_ctx.semi[1];
+                    react.z = -fw.z * (xi.z - dl.z) / s_ctx.semi[2];
+                }
+                if (MODE == GD_MODE_ENERGY) E += e;
+            }
+        }
+
+        if (MODE == GD_MODE_STEP) {
+            // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
+            const float mu_dt = p.mob[g] * p.dt;
+            float3 z = make_float3(0.f, 0.f, 0.f);
+            if (p.kT > 0.f) {
+                const unsigned o = p.orig[g];
+                if (p.noise_mode == NOISE_PHILOX) z = philox_normal3(p.seed, o, s_ctx.step + 1, r);
+                else if (p.noise_mode == NOISE_HOST) {
+                    const float *h = p.host_noise + ((size_t)r * p.N + o) * 3;
+                    z = make_float3(h[0], h[1], h[2]);
+                }
+            }
+            const float sg = sqrtf(2.0f * p.kT * mu_dt);
+            p.pos_out[g] = make_float4(xi.x + mu_dt * F.x + sg * z.x, xi.y + mu_dt * F.y + sg * z.y,
+                                       xi.z + mu_dt * F.z + sg * z.z, xi4.w);
+        } else if (MODE == GD_MODE_FORCE) {
+            p.fout[(size_t)r * p.N + p.orig[g]] = make_float4(F.x, F.y, F.z, 0.f);
+        }
+    }
+
+    // ---- block reductions: wall reaction partial (deterministic), energy, max displacement
+    if (p.wall.enabled && MODE != GD_MODE_ENERGY) {
+        const float sx = wave_sum_f(react.x), sy = wave_sum_f(react.y), sz = wave_sum_f(react.z);
+        if (lane == 0) { s_red[wid][0] = sx; s_red[wid][1] = sy; s_red[wid][2] = sz; }
+        __syncthreads();
+        if (tid == 0) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int w = 0; w < GD_BLOCK / 64; w++) { v.x += s_red[w][0]; v.y += s_red[w][1]; v.z += s_red[w][2]; }
+            p.react_part[(size_t)r * p.nblk + blk] = v;
+        }
+    }
+    if (MODE == GD_MODE_ENERGY) {
+        const double se = wave_sum_d((double)E);
+        if (lane == 0) s_e[wid] = se;
+        __syncthreads();
+        if (tid == 0) {
+            double v = 0;
+            for (int w = 0; w < GD_BLOCK / 64; w++) v += s_e[w];
+            p.epart[(size_t)r * p.nblk + blk] = v;
+        }
+    }
+    if (MODE == GD_MODE_STEP && p.record_disp) {
+        const float m = wave_max_f(disp2);
+        if (lane == 0) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_MAXDISP2], __float_as_uint(m));
+    }
+}
+
+// Applies the pending callback of the last step (end of gd_run) / folds reaction partials into ctx.
+__global__ __launch_bounds__(64) void k_finalize(const StepParams p, int reduce_only)
+{
+    const unsigned r = blockIdx.x, lane = threadIdx.x;
+    DevCtx c = p.ctx_in[r];
+    if (reduce_only) {
+        double rx = 0, ry = 0, rz = 0;
+        for (unsigned b = lane; b < p.nblk; b += 64) {
+            const float4 v = p.react_part[(size_t)r * p.nblk + b];
+            rx += v.x; ry += v.y; rz += v.z;
+        }
+        c.react[0] = wave_sum_d(rx); c.react[1] = wave_sum_d(ry); c.react[2] = wave_sum_d(rz);
+    } else if (c.pending) {
+        apply_callback(c, p, r, lane);
+    }
+    if (lane == 0) p.ctx_out[r] = c;
+}
+
+void gd_launch_step(const StepParams &p, int mode, hipStream_t st)
+{
+    const dim3 grid(p.R * p.nblk), block(GD_BLOCK);
+#define LAUNCH(M)                                                                     \
+    do {                                                                              \
+        if (p.periodic) hipLaunchKernelGGL((k_step<M, true>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((k_step<M, false>), grid, block, 0, st, p);           \
+    } while (0)
+    if (mode == GD_MODE_STEP) LAUNCH(GD_MODE_STEP);
+    else if (mode == GD_MODE_FORCE) LAUNCH(GD_MODE_FORCE);
+    else LAUNCH(GD_MODE_ENERGY);
+#undef LAUNCH
+}
+
+void gd_launch_finalize(const StepParams &p, int reduce_only, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(p.R), dim3(64), 0, st, p, reduce_only);
+}
+
+// --------------------------------------------------------- neighbour search
+
+__global__ void k_build_init(const BuildParams p)
+{
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.R) return;
+    p.lcount[r] = 0ull;
+}
+
+// per-block bounding box partials (open box): bbox[(r*nblk + blk)*6 + {lo xyz, hi xyz}]
+__global__ __launch_bounds__(GD_BLOCK) void k_bbox(const BuildParams p)
+{
+    __shared__ float s_lo[GD_BLOCK / 64][3], s_hi[GD_BLOCK / 64][3];
+    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (slot < p.N) {
+        const float4 x = p.pos_in[(size_t)r * p.Np + slot];
+        lo[0] = hi[0] = x.x; lo[1] = hi[1] = x.y; lo[2] = hi[2] = x.z;
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int o = 32; o > 0; o >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64)); }
+        if (lane == 0) { s_lo[wid][k] = lo[k]; s_hi[wid][k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float l = s_lo[0][k], h = s_hi[0][k];
+        for (int w = 1; w < GD_BLOCK / 64; w++) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
+        p.bbox[((size_t)r * p.nblk + blk) * 6 + k] = l;
+        p.bbox[((size_t)r * p.nblk + blk) * 6 + 3 + k] = h;
+    }
+}
+
+// one wave per replica: reduce the bounding box and choose the cell grid
+__global__ __launch_bounds__(64) void k_gridp(const BuildParams p)
+{
+    const unsigned r = blockIdx.x, lane = threadIdx.x;
+    float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, e0 = p.box[0], e1 = p.box[1], e2 = p.box[2];
+    const int extra = p.periodic ? 0 : 1;
+    if (!p.periodic) {
+        float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, h0 = -INFINITY, h1 = -INFINITY, h2 = -INFINITY;
+        for (unsigned b = lane; b < p.nblk; b += 64) {
+            const float *bb = p.bbox + ((size_t)r * p.nblk + b) * 6;
+            l0 = fminf(l0, bb[0]); l1 = fminf(l1, bb[1]); l2 = fminf(l2, bb[2]);
+            h0 = fmaxf(h0, bb[3]); h1 = fmaxf(h1, bb[4]); h2 = fmaxf(h2, bb[5]);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            l0 = fminf(l0, __shfl_xor(l0, o, 64)); l1 = fminf(l1, __shfl_xor(l1, o, 64)); l2 = fminf(l2, __shfl_xor(l2, o, 64));
+            h0 = fmaxf(h0, __shfl_xor(h0, o, 64)); h1 = fmaxf(h1, __shfl_xor(h1, o, 64)); h2 = fmaxf(h2, __shfl_xor(h2, o, 64));
+        }
+        lo0 = l0; lo1 = l1; lo2 = l2;
+        e0 = h0 - l0; e1 = h1 - l1; e2 = h2 - l2;
+        if (!(e0 > 0.f)) e0 = p.rv;
+        if (!(e1 > 0.f)) e1 = p.rv;
+        if (!(e2 > 0.f)) e2 = p.rv;
+    }
+    // cells >= rv; grow the cell size until the cell count fits the allocation
+    float cs = p.rv;
+    int n0 = 1, n1 = 1, n2 = 1;
+    for (int it = 0; it < 64; it++) {
+        n0 = max((int)floorf(e0 / cs) + extra, 1);
+        n1 = max((int)floorf(e1 / cs) + extra, 1);
+        n2 = max((int)floorf(e2 / cs) + extra, 1);
+        if ((float)n0 * (float)n1 * (float)n2 <= (float)p.ncell_cap) break;
+        cs *= 1.26f;
+    }
+    if (lane == 0) {
+        GridP *g = p.grid + r;
+        g->org[0] = lo0; g->org[1] = lo1; g->org[2] = lo2;
+        if (p.periodic) { g->inv[0] = (float)n0 / e0; g->inv[1] = (float)n1 / e1; g->inv[2] = (float)n2 / e2; }
+        else { g->inv[0] = 1.0f / cs; g->inv[1] = 1.0f / cs; g->inv[2] = 1.0f / cs; }
+        g->nc[0] = n0; g->nc[1] = n1; g->nc[2] = n2;
+        g->ncell = n0 * n1 * n2;
+    }
+}
+
+template <bool PERIODIC>
+__device__ __forceinline__ void cell_coords(const GridP &g, const float4 x, const float *inv_box, int &cx, int &cy, int &cz)
+{
+    if (PERIODIC) {
+        float fx = x.x * inv_box[0], fy = x.y * inv_box[1], fz = x.z * inv_box[2];
+        fx -= floorf(fx); fy -= floorf(fy); fz -= floorf(fz);
+        cx = min((int)(fx * g.nc[0]), g.nc[0] - 1);
+        cy = min((int)(fy * g.nc[1]), g.nc[1] - 1);
+        cz = min((int)(fz * g.nc[2]), g.nc[2] - 1);
+    } else {
+        cx = min(max((int)floorf((x.x - g.org[0]) * g.inv[0]), 0), g.nc[0] - 1);
+        cy = min(max((int)floorf((x.y - g.org[1]) * g.inv[1]), 0), g.nc[1] - 1);
+        cz = min(max((int)floorf((x.z - g.org[2]) * g.inv[2]), 0), g.nc[2] - 1);
+    }
+}
+
+template <bool PERIODIC>
+__global__ __launch_bounds__(GD_BLOCK) void k_bin(const BuildParams p)
+{
+    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x;
+    if (slot >= p.N) return;
+    const size_t g = (size_t)r * p.Np + slot;
+    const GridP gp = p.grid[r];
+    int cx, cy, cz;
+    cell_coords<PERIODIC>(gp, p.pos_in[g], p.inv_box, cx, cy, cz);
+    const unsigned c = (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx);
+    p.cell_id[g] = c;
+    p.rank[g] = atomicAdd(&p.cell_cnt[(size_t)r * (p.ncell_cap + 1) + c], 1u);
+}
+
+// exclusive scan of the cell counts of one replica (one 1024-thread block per replica)
+__global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
+{
+    __shared__ unsigned s_sum[1024];
+    const unsigned r = blockIdx.x, tid = threadIdx.x;
+    const unsigned n = (unsigned)p.grid[r].ncell;
+    const unsigned *cnt = p.cell_cnt + (size_t)r * (p.ncell_cap + 1);
+    unsigned *start = p.cell_start + (size_t)r * (p.ncell_cap + 1);
+    const unsigned chunk = (n + 1023u) / 1024u;
+    const unsigned b = tid * chunk, e = min(b + chunk, n);
+    unsigned s = 0;
+    for (unsigned c = b; c < e; c++) s += cnt[c];
+    s_sum[tid] = s;
+    __syncthreads();
+    for (unsigned o = 1; o < 1024; o <<= 1) {
+        unsigned v = tid >= o ? s_sum[tid - o] : 0u;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_sum[tid] - s;
+    for (unsigned c = b; c < e; c++) { start[c] = run; run += cnt[c]; }
+    if (tid == 1023) start[n] = s_sum[1023];
+}
+
+__global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
+{
+    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x;
+    if (slot >= p.N) return;
+    const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
+    const unsigned ns = p.cell_start[(size_t)r * (p.ncell_cap + 1) + p.cell_id[g]] + p.rank[g];
+    const unsigned o = p.orig_in[g];
+    const float4 x = p.pos_in[g];
+    const size_t gn = rbase + ns;
+    p.pos_out[gn] = x;
+    p.xb[gn] = x;
+    p.orig_out[gn] = o;
+    p.slot_of[(size_t)r * p.N + o] = ns;
+    p.ab[gn] = p.ab_o[o];
+    p.mob[gn] = p.mob_o[o];
+    p.bendE[gn] = p.bendE_o[o];
+    p.psmask[gn] = p.psmask_o[o];
+    p.bdeg[gn] = p.bdeg_o[o];
+}
+
+// Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
+template <bool PERIODIC>
+__global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
+{
+    __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
+    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
+    unsigned cnt = 0;
+    if (slot < p.N) {
+        const unsigned o = p.orig_out[g];
+        const unsigned *so = p.slot_of + (size_t)r * p.N;
+        const unsigned deg = p.bdeg_o[o];
+        for (unsigned k = 0; k < deg; k++) {
+            const unsigned ent = p.badj_o[(size_t)k * p.N + o];
+            p.badj[(size_t)k * p.stride + g] = so[ent & GD_ADJ_MASK] | (ent & ~GD_ADJ_MASK);
+        }
+        if (p.chain_o) {
+            int4 c = p.chain_o[o];
+            c.x = c.x >= 0 ? (int)so[c.x] : -1; c.y = c.y >= 0 ? (int)so[c.y] : -1;
+            c.z = c.z >= 0 ? (int)so[c.z] : -1; c.w = c.w >= 0 ? (int)so[c.w] : -1;
+            p.chain[g] = c;
+        }
+        if (p.nbr) {
+            const GridP gp = p.grid[r];
+            const float4 xi = p.pos_out[g];
+            const float4 *__restrict__ rpos = p.pos_out + rbase;
+            const unsigned *__restrict__ cs = p.cell_start + (size_t)r * (p.ncell_cap + 1);
+            int cx, cy, cz;
+            cell_coords<PERIODIC>(gp, xi, p.inv_box, cx, cy, cz);
+            const float rv2 = p.rv * p.rv;
+            // distinct neighbour cells per dimension (small periodic grids alias)
+            const int nz = PERIODIC ? min(3, gp.nc[2]) : 3, ny = PERIODIC ? min(3, gp.nc[1]) : 3, nx = PERIODIC ? min(3, gp.nc[0]) : 3;
+            const int z0 = (PERIODIC && gp.nc[2] < 3) ? 0 : cz - 1, y0 = (PERIODIC && gp.nc[1] < 3) ? 0 : cy - 1,
+                      x0 = (PERIODIC && gp.nc[0] < 3) ? 0 : cx - 1;
+            unsigned *__restrict__ col = p.nbr + g;
+            for (int iz = 0; iz < nz; iz++) {
+                int zz = z0 + iz;
+                if (PERIODIC) zz = (zz + gp.nc[2]) % gp.nc[2]; else if (zz < 0 || zz >= gp.nc[2]) continue;
+                for (int iy = 0; iy < ny; iy++) {
+                    int yy = y0 + iy;
+                    if (PERIODIC) yy = (yy + gp.nc[1]) % gp.nc[1]; else if (yy < 0 || yy >= gp.nc[1]) continue;
+                    for (int ix = 0; ix < nx; ix++) {
+                        int xx = x0 + ix;
+                        if (PERIODIC) xx = (xx + gp.nc[0]) % gp.nc[0]; else if (xx < 0 || xx >= gp.nc[0]) continue;
+                        const unsigned c = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0] + xx);
+                        const unsigned b = cs[c], e = cs[c + 1];
+                        for (unsigned j = b; j < e; j++) {
+                            if (j == slot) continue;
+                            const float4 xj = rpos[j];
+                            float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+                            if (PERIODIC) d = min_image(d, p.box, p.inv_box);
+                            if (d.x * d.x + d.y * d.y + d.z * d.z < rv2) {
+                                if (cnt < p.W) col[(size_t)cnt * p.stride] = j;
+                                cnt++;
+                            }
+                        }
+                    }
+                }
+            }
+            if (cnt > p.W) {
+                p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
+                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], cnt);
+            }
+            p.ncnt[g] = min(cnt, p.W);
+        }
+    }
+    unsigned long long c64 = min(cnt, p.W);
+    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o, 64);
+    if (lane == 0) s_cnt[wid] = c64;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < GD_BLOCK / 64; w++) t += s_cnt[w];
+        if (t) atomicAdd(&p.lcount[r], t);
+    }
+}
+
+void gd_launch_build(const BuildParams &p, hipStream_t st)
+{
+    const dim3 grid(p.R * p.nblk), block(GD_BLOCK);
+    hipLaunchKernelGGL(k_build_init, dim3((p.R + 63) / 64), dim3(64), 0, st, p);
+    if (!p.periodic) hipLaunchKernelGGL(k_bbox, grid, block, 0, st, p);
+    hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(64), 0, st, p);
+    (void)hipMemsetAsync(p.cell_cnt, 0, (size_t)p.R * (p.ncell_cap + 1) * sizeof(unsigned), st);
+    if (p.periodic) hipLaunchKernelGGL(k_bin<true>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(k_bin<false>, grid, block, 0, st, p);
+    hipLaunchKernelGGL(k_scan, dim3(p.R), dim3(1024), 0, st, p);
+    hipLaunchKernelGGL(k_scatter, grid, block, 0, st, p);
+    if (p.periodic) hipLaunchKernelGGL(k_fill<true>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(k_fill<false>, grid, block, 0, st, p);
+}
+
+// ------------------------------------------------------------------- misc
+
+__global__ void k_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np, int quantize)
+{
+    const unsigned r = blockIdx.y, o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    float4 x = pos[(size_t)r * Np + slot_of[(size_t)r * N + o]];
+    if (quantize) {
+        // simulation_common/simulation_store.cc:403-407: 16 fractional bits
+        x.x = rintf(x.x * 65536.0f) * (1.0f / 65536.0f);
+        x.y = rintf(x.y * 65536.0f) * (1.0f / 65536.0f);
+        x.z = rintf(x.z * 65536.0f) * (1.0f / 65536.0f);
+    }
+    out[(size_t)r * N + o] = x;
+}
+
+void gd_launch_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np, unsigned R,
+                                int quantize, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gather_positions, dim3((N + 255) / 256, R), dim3(256), 0, st, pos, slot_of, out, N, Np, quantize);
+}
+
+__global__ void k_identity(unsigned *orig, unsigned *slot_of, unsigned N, unsigned Np)
+{
+    const unsigned r = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= Np) return;
+    orig[(size_t)r * Np + s] = s < N ? s : 0xffffffffu;
+    if (s < N) slot_of[(size_t)r * N + s] = s;
+}
+
+void gd_launch_identity(unsigned *orig, unsigned *slot_of, unsigned N, unsigned Np, unsigned R, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_identity, dim3((Np + 255) / 256, R), dim3(256), 0, st, orig, slot_of, N, Np);
+}

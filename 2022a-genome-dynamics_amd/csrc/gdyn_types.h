@@ -1,0 +1,168 @@
+// gdyn_types.h -- structures shared by the host side (gdyn_capi.hip) and the kernels
+// (gdyn_kernels.hip).  Layout in HBM (DESIGN.md "Data layout"):
+//   * beads of one replica live in SLOT order: slots are re-assigned by a counting sort
+//     over the neighbour-search cells at every list build, so that spatial neighbours are
+//     memory neighbours (coalesced loads, L1/L2-local gathers).  orig[] / slot_of[] map
+//     between slot order and the caller's bead (chain) order.
+//   * every per-slot array is replica-major with stride Np (N padded to the block size):
+//     element (replica r, slot s) is at r*Np + s.
+//   * lists are ELL, column-major: entry k of slot g is at k*(R*Np) + g (coalesced).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GD_BLOCK 256
+#define GD_MAX_BOND_TYPES 64
+#define GD_MAX_POINT_SOURCES 4
+#define GD_ADJ_SHIFT 26                    // bond adjacency entry = partner | type << 26
+#define GD_ADJ_MASK ((1u << GD_ADJ_SHIFT) - 1u)
+
+enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
+
+// flags[r*GD_NFLAGS + k]
+enum { GD_FLAG_VIOLATION = 0, GD_FLAG_OVERFLOW = 1, GD_FLAG_MAXDISP2 = 2, GD_FLAG_NEED_W = 3, GD_NFLAGS = 4 };
+
+struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
+    long long step;
+    int pending;                // 1: the callback of step `step+1` has not been applied yet
+    int pad;
+    double time, bead_scale, bond_scale;
+    double semi[3];
+    double react[3];            // axial_reaction of the last force evaluation
+};
+
+struct GridP {                  // per replica cell grid of the last list build
+    float org[3];
+    float inv[3];               // 1 / cell size
+    int nc[3];
+    int ncell;
+};
+
+struct PairP {
+    float eps_a, sigma_a, eps_b, sigma_b;
+    int p_a, q_a, p_b, q_b;
+    int mix, scaled, enabled;
+    float cutoff;               // max(sigma with eps != 0), unscaled
+};
+
+struct WallP {
+    float eps_a, sigma_a, eps_b, sigma_b;
+    int p_a, q_a, p_b, q_b;
+    float wall_a, wall_b;
+    int scaled, enabled;
+    float packing_spring;
+    double spring[3], mobility;
+};
+
+struct BondType {
+    int kind, mix, scaled, p, q, minimg, term;
+    float ka, kb, la, lb;
+};
+
+struct PointSrc {
+    int kind;
+    float k, b, p[3];
+};
+
+struct ScaleP {
+    int enabled;
+    double bead_init, bead_tau, bond_init, bond_tau;
+};
+
+struct StepParams {
+    // sizes
+    unsigned N, Np, R, nblk;            // nblk = blocks per replica
+    size_t stride;                      // R*Np, ELL column stride
+    int periodic;
+    float box[3], inv_box[3];
+    // per-slot state
+    const float4 *pos_in;
+    float4 *pos_out;
+    const float4 *xb;                   // positions at list build
+    const unsigned *orig;
+    const float2 *ab;
+    const float *mob;
+    const float4 *bendE;                // (e_last, e_mid, e_first, -) bending energies of the 3 triplets a bead is in
+    const unsigned char *psmask;
+    // lists
+    const unsigned *nbr;
+    const unsigned *ncnt;
+    unsigned W;
+    const unsigned *badj;
+    const unsigned char *bdeg;
+    const int4 *chain;                  // slots of (i-2, i-1, i+1, i+2) or -1
+    // context
+    const DevCtx *ctx_in;
+    DevCtx *ctx_out;
+    float4 *react_part;                 // [R][nblk]
+    unsigned *flags;
+    // model
+    PairP pair;
+    WallP wall;
+    ScaleP scaling;
+    const BondType *btab;
+    int nbt;
+    PointSrc ps[GD_MAX_POINT_SOURCES];
+    int nps;
+    int has_bend, has_bonds;
+    // run
+    double dt_d;
+    float dt, kT;
+    unsigned long long seed;
+    int noise_mode, run_flags;
+    const float *host_noise;            // (R, N, 3) normals of this step
+    float rv;                           // list radius (violation check)
+    int record_disp;
+    // force / energy modes
+    unsigned term_mask;
+    float4 *fout;                       // [R][N] by bead index
+    double *epart;                      // [R][nblk]
+};
+
+struct BuildParams {
+    unsigned N, Np, R, nblk;
+    size_t stride;
+    int periodic;
+    float box[3], inv_box[3];
+    float rv;
+    unsigned ncell_cap;
+    const float4 *pos_in;               // current order
+    float4 *pos_out;                    // new (sorted) order
+    float4 *xb;
+    const unsigned *orig_in;
+    unsigned *orig_out;
+    unsigned *slot_of;                  // [R][N]
+    unsigned *cell_id, *rank;           // [R*Np]
+    unsigned *cell_cnt, *cell_start;    // [R][ncell_cap+1]
+    float *bbox;                        // [R][nblk][6] per-block bounding-box partials
+    GridP *grid;
+    // static per-bead (bead order)
+    const float2 *ab_o;
+    const float *mob_o;
+    const float4 *bendE_o;
+    const unsigned char *psmask_o;
+    const unsigned *badj_o;             // [WB][N]
+    const unsigned char *bdeg_o;
+    const int4 *chain_o;
+    unsigned WB;
+    // slot-order outputs
+    float2 *ab;
+    float *mob;
+    float4 *bendE;
+    unsigned char *psmask;
+    unsigned *badj;
+    unsigned char *bdeg;
+    int4 *chain;
+    unsigned *nbr, *ncnt;
+    unsigned W;
+    unsigned *flags;
+    unsigned long long *lcount;         // [R] directed list entries
+};
+
+// launchers (gdyn_kernels.hip)
+void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
+void gd_launch_finalize(const StepParams &p, int reduce_only, hipStream_t st);
+void gd_launch_build(const BuildParams &p, hipStream_t st);
+void gd_launch_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np,
+                                unsigned R, int quantize, hipStream_t st);
+void gd_launch_identity(unsigned *orig, unsigned *slot_of, unsigned N, unsigned Np, unsigned R, hipStream_t st);

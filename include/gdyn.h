@@ -1,0 +1,272 @@
+/* gdyn.h -- C-ABI of libgdyn: the MI355X Brownian-dynamics stepper.
+ *
+ * This is the one boundary the build cuts through the reference
+ * (snsinfu/2022a-genome-dynamics): the set of micromd (<md.hpp>) calls that the
+ * reference's simulation drivers make.  Every entry point below cites the
+ * reference call site (path:line relative to the reference root) it replaces.
+ * Reference potentials are arbitrary C++ lambdas; they cannot cross a C-ABI, so
+ * the closed set of parameterised families the drivers actually instantiate is
+ * exposed instead.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host arrays are caller-owned.
+ *   - positions/forces on the boundary are fp64 (md::point is 3 doubles,
+ *     3-sim-1kb/src/simulation/buffer_traits.hpp:15-30), shape (R, N, 3),
+ *     replica-major; the device computes in fp32.
+ *   - every function returns a gd_status; gd_last_error() gives the message.
+ *     No C++ exception crosses the boundary.
+ *   - a handle is bound to one HIP device and one stream; it is not
+ *     thread-safe; independent handles may live on different threads/devices.
+ *   - "bead index" is the index in the caller's (chain) order, always.
+ */
+#ifndef GDYN_H
+#define GDYN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gd_system gd_system;
+
+typedef enum {
+    GD_OK = 0,
+    GD_EINVAL = 1,       /* bad argument (index out of range, NULL, unsupported power ...) */
+    GD_ENODEVICE = 2,    /* no HIP device / HIP extension unusable */
+    GD_EHIP = 3,         /* a HIP runtime call failed */
+    GD_ENOMEM = 4,
+    GD_ESTATE = 5,       /* call sequence error (e.g. topology change after first run) */
+    GD_EUNSUPPORTED = 6  /* e.g. spacestep != 0 (adaptive step; micromd-internal rule unknown) */
+} gd_status;
+
+const char *gd_last_error(void);
+/* "hip" for the product library, "oracle" for oracle/liboracle (tests only). */
+const char *gd_backend_name(void);
+
+/* ------------------------------------------------------------------ system */
+
+enum { GD_BOX_OPEN = 0, GD_BOX_PERIODIC = 1 };
+
+typedef struct {
+    uint32_t n_beads;      /* N: md::system::add_particle() count
+                              (5-sim-genome/src/simulation_interphase/simulation_driver_particles.cc:17-20) */
+    uint32_t n_replicas;   /* R independent trajectories stepped in one launch (new: the
+                              reference runs one process per seed, 5-sim-genome/scripts/run_simulation:8-25) */
+    int32_t  device;       /* HIP device ordinal */
+    int32_t  box_kind;     /* GD_BOX_OPEN | GD_BOX_PERIODIC (md::periodic_box,
+                              3-sim-1kb/src/simulation/simulation.cpp:118-123) */
+    double   box[3];       /* x/y/z period when periodic */
+} gd_desc;
+
+int gd_create(const gd_desc *desc, gd_system **out);
+int gd_destroy(gd_system *sys);
+
+/* md::system::view_positions() (simultion_driver_relaxation.cc:12-15). (R,N,3) fp64. */
+int gd_set_positions(gd_system *sys, const double *xyz);
+int gd_get_positions(gd_system *sys, double *xyz);
+/* Snapshot path: (R,N,3) fp32; quantize != 0 rounds to multiples of 2^-16 on the
+ * device exactly as simulation_common/simulation_store.cc:257-268,403-407 does on the host. */
+int gd_get_positions_f32(gd_system *sys, float *xyz, int quantize);
+
+/* Per-bead attributes, shared by all replicas; any pointer may be NULL (keeps default).
+ *   a_factor,b_factor: particle_data (simulation_common/particle_data.hpp:6-13), default 0,0
+ *   mobility:          view_mobilities() (simulation_driver_particles.cc:25-35), default 1
+ *   bending_energy:    monomer_data (3-sim-1kb/src/simulation/simulation.cpp:21-26,66-79), default 0 */
+int gd_set_bead_params(gd_system *sys, const double *a_factor, const double *b_factor,
+                       const double *mobility, const double *bending_energy);
+
+/* ------------------------------------------------------- non-bonded (a3,a5) */
+
+/* a*softcore<PA,QA>{eps_a,sigma_a} + b*softcore<PB,QB>{eps_b,sigma_b} over a Verlet
+ * neighbour list; neighbour distance = max(sigma) (x bead_scale when scaled).
+ *   mix=1: a=(a_i+a_j)/2, b=(b_i+b_j)/2  (simulation_driver_forcefield.cc:30-45,
+ *          4-sim-ab/box/src/simulation/simulation_driver.cc:107-113)
+ *   mix=0: a=b=1                          (3-sim-1kb/src/simulation/simulation.cpp:102-124,
+ *          simulation_spindle/simulation_driver.cc:94-102 with eps_b=0)
+ * softcore<P,Q>: U = eps*(1-(r/sigma)^P)^Q for r<sigma, P even in {2,4,6,8,12}, Q in {1,2,3,4}.
+ * eps may be negative (attraction). Periodic systems use the minimum image. */
+typedef struct {
+    double  eps_a, sigma_a;
+    double  eps_b, sigma_b;
+    int32_t p_a, q_a, p_b, q_b;
+    int32_t mix;
+    int32_t scale_by_bead_scale;   /* sigma *= bead_scale(t), simulation_driver_forcefield.cc:37,41,48 */
+} gd_pair_softcore;
+
+int gd_set_pair_softcore(gd_system *sys, const gd_pair_softcore *p);
+
+/* ------------------------------------------------------------- bonded (a6) */
+
+enum {
+    GD_POT_HARMONIC = 0,    /* U = K r^2 / 2                      md::harmonic_potential   */
+    GD_POT_SPRING = 1,      /* U = K (r-b)^2 / 2                  md::spring_potential     */
+    GD_POT_SEMISPRING = 2,  /* U = K (r-b)^2 / 2 for r>b else 0   md::semispring_potential */
+    GD_POT_SOFTCORE = 3     /* U = k_a (1-(r/l_a)^p)^q, r<l_a     md::softcore_potential (glue_forcefield.cpp:12) */
+};
+
+typedef struct {
+    int32_t kind;
+    int32_t mix;                 /* 1: K=a*k_a+b*k_b, l=a*l_a+b*l_b with a,b the pair means
+                                    (simulation_driver_forcefield.cc:60-70); 0: K=k_a, l=l_a */
+    double  k_a, k_b, l_a, l_b;
+    int32_t scale_by_bond_scale; /* K/=s^2, l*=s  (simulation_driver_forcefield.cc:72-77) */
+    int32_t p, q;                /* GD_POT_SOFTCORE only */
+    int32_t minimum_image;       /* periodic_box::shortest_displacement (glue_forcefield.cpp:38) */
+} gd_bond_params;
+
+/* add_bonded_range(start,end): bonds (i,i+stride) for start <= i, i+stride < end.
+ * stride 1 = chain bonds (simulation_driver_forcefield.cc:86-88);
+ * stride 2 = the (i,i+2) "loop" bonds (simulation_driver_forcefield.cc:123-127). */
+int gd_add_bond_range(gd_system *sys, const gd_bond_params *p,
+                      uint32_t start, uint32_t end, uint32_t stride);
+/* add_bonded_pair(i,j) xn (simulation_driver_forcefield.cc:149-151). pairs = n x 2. */
+int gd_add_bond_pairs(gd_system *sys, const gd_bond_params *p,
+                      const uint32_t *pairs, uint32_t n);
+/* Re-uploadable pair lists evaluated inside the step: the custom md::forcefield
+ * subclasses loop_forcefield / glue_forcefield (3-sim-1kb/src/simulation/forces/
+ * loop_forcefield.cpp:36-50, glue_forcefield.cpp:32-44). slot in [0,4). */
+int gd_set_dynamic_pairs(gd_system *sys, uint32_t slot, const gd_bond_params *p,
+                         const uint32_t *pairs, uint32_t n);
+
+/* ------------------------------------------------------------ bending (a7) */
+
+/* make_bonded_triplewise_forcefield(cosine_bending_potential).add_bonded_range(start,end):
+ * triplets (i,i+1,i+2), U = e (1 - cos theta).  per_bead=0: e = energy
+ * (simulation_spindle/simulation_driver.cc:119-130); per_bead=1: e = bending_energy of
+ * the MIDDLE bead (3-sim-1kb/src/simulation/simulation.cpp:146-159). */
+int gd_add_bending_range(gd_system *sys, uint32_t start, uint32_t end,
+                         double energy, int per_bead);
+
+/* ------------------------------------------------------- point source (a8) */
+
+/* make_point_source_forcefield(pot).set_point_source(p)[.set_point_source_targets(idx)]
+ * (simulation_spindle/simulation_driver.cc:147-155,163-171). kind: HARMONIC{K} or
+ * SEMISPRING{K,b}. targets NULL => all beads. At most 4 sources. */
+int gd_add_point_source(gd_system *sys, int kind, double k, double b,
+                        const double point[3], const uint32_t *targets, uint32_t n_targets);
+
+/* ------------------------------------------------- ellipsoid wall (a9,a11) */
+
+typedef struct {
+    /* inward: a_w*softcore<p_a,q_a>{eps_a, sigma_a/2 * bead_scale} + b_w*softcore<p_b,q_b>{...}
+     * with a_w=(a_i+wall_a_factor)/2, b_w=(b_i+wall_b_factor)/2
+     * (simulation_driver_forcefield.cc:196-214). sigma_* are FULL diameters here. */
+    double  eps_a, sigma_a, eps_b, sigma_b;
+    int32_t p_a, q_a, p_b, q_b;
+    double  wall_a_factor, wall_b_factor;
+    int32_t scale_by_bead_scale;
+    /* outward: harmonic_potential{packing_spring} (simulation_driver_forcefield.cc:220-226) */
+    double  packing_spring;
+    /* wall ODE, simulation_driver_interphase.cc:70-80:
+     * semiaxes += dt * mobility * (axial_reaction - semiaxes_spring (.) semiaxes) */
+    double  semiaxes_spring[3];
+    double  mobility;
+    double  init_semiaxes[3];
+} gd_wall;
+
+int gd_set_ellipsoid_wall(gd_system *sys, const gd_wall *w);
+
+/* --------------------------------------------------- per-step context (a11) */
+
+/* bead_scale(t) = 1-(1-init)exp(-t/tau), same for bond_scale
+ * (simulation_driver_interphase.cc:59-67). Initial context = {init, init}
+ * (simulation_interphase/simulation_driver.cc:43-51). */
+int gd_set_scaling(gd_system *sys, double bead_scale_init, double bead_scale_tau,
+                   double bond_scale_init, double bond_scale_tau);
+
+typedef struct {
+    int64_t  step;           /* steps taken in the current phase */
+    double   time;           /* step * timestep of the last run */
+    double   bead_scale, bond_scale;
+    double   semiaxes[3];
+    double   axial_reaction[3];   /* stats.axial_reaction of the last force evaluation */
+    /* diagnostics (not part of the reference's state) */
+    uint64_t list_entries;   /* L: directed neighbour-list entries currently stored */
+    uint64_t rebuilds;       /* neighbour-list builds since creation */
+    uint64_t rollbacks;      /* verified-skin rollbacks since creation */
+    uint32_t rebuild_interval;
+    double   list_radius;
+} gd_context;
+
+int gd_get_context(gd_system *sys, uint32_t replica, gd_context *out);
+/* Start a phase: step=0, time=0, semiaxes as given (NULL keeps), scales re-evaluated at t=0.
+ * Mirrors the drivers' setup_context() + the driver-called callback(0). */
+int gd_begin_phase(gd_system *sys, const double *semiaxes /* (R,3) or NULL */);
+/* Restart support (simulation_fine_sampling/simulation_driver.cc:44-54). */
+int gd_set_context(gd_system *sys, uint32_t replica, int64_t step,
+                   double bead_scale, double bond_scale, const double semiaxes[3]);
+
+/* ---------------------------------------------------------- stepping (a1) */
+
+enum { GD_NOISE_PHILOX = 0, GD_NOISE_ZERO = 1, GD_NOISE_HOST = 2 };
+enum {
+    GD_RUN_UPDATE_SCALES = 1,   /* callback runs update_bead_scale()   (simulation_driver_interphase.cc:42) */
+    GD_RUN_WALL_DYNAMICS = 2    /* callback runs update_wall_semiaxes() (simulation_driver_interphase.cc:43) */
+};
+
+/* md::simulate_brownian_dynamics(system, {temperature,timestep,spacestep,steps,seed,callback})
+ * (simulation_driver_interphase.cc:48-55): for k=1..steps
+ *     x_i += mu_i F_i dt + sqrt(2 mu_i kT dt) xi_i ;  callback(k)
+ * The callback's per-step state updates run on the device (flags); everything else a
+ * callback does (logging, sampling) is done by the caller between gd_run() chunks. */
+typedef struct {
+    double   temperature;
+    double   timestep;
+    double   spacestep;     /* must be 0 (all reference defaults, config_entries.inc:61,71,79) */
+    int64_t  steps;
+    uint64_t seed;          /* replica r draws from stream (seed, r) */
+    int32_t  noise_mode;
+    int32_t  flags;
+    const double *host_noise;   /* GD_NOISE_HOST: (steps, R, N, 3) standard normals */
+} gd_run_desc;
+
+int gd_run(gd_system *sys, const gd_run_desc *run);
+
+/* ------------------------------------------------------------- observation */
+
+enum {
+    GD_TERM_PAIR = 1, GD_TERM_BOND = 2, GD_TERM_BEND = 4, GD_TERM_POINT = 8,
+    GD_TERM_WALL = 16, GD_TERM_DYNAMIC = 32, GD_TERM_ALL = 63
+};
+
+/* md::system::compute_energy() (simulation_driver_interphase.cc:20-22): per replica. */
+int gd_compute_energy(gd_system *sys, uint32_t term_mask, double *energy /* (R) */);
+/* Forces on the current positions under the current context, (R,N,3) fp64;
+ * also refreshes axial_reaction. Parity/diagnostic entry point. */
+int gd_compute_forces(gd_system *sys, uint32_t term_mask, double *forces);
+
+/* md::neighbor_searcher<Box>{box,dcut}.set_points().search(out)
+ * (simulation_interphase/contact_map.cc:64-66): unique pairs i<j within dcut of
+ * replica `replica`; writes up to cap pairs, returns the total in *n_pairs. */
+int gd_search_pairs(gd_system *sys, uint32_t replica, double dcut,
+                    uint32_t *pairs, uint64_t cap, uint64_t *n_pairs);
+
+/* --------------------------------------------------------- tuning / timing */
+
+typedef struct {
+    double   skin;              /* Verlet skin as a fraction of the cutoff (default 0.5) */
+    uint32_t rebuild_interval;  /* initial steps between list builds; 0 = auto */
+    uint32_t adapt_interval;    /* 1 = adapt interval from measured displacements */
+    uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
+    uint32_t use_graph;         /* replay steps from a hipGraph */
+} gd_tuning;
+
+int gd_set_tuning(gd_system *sys, const gd_tuning *t);
+
+typedef struct {
+    double   step_kernel_ms;    /* HIP-event time of the step kernels in the last gd_run */
+    double   rebuild_ms;        /* HIP-event time of the list builds in the last gd_run  */
+    double   total_ms;          /* HIP-event time of the whole enqueued region           */
+    uint64_t step_launches, rebuild_launches;
+    uint64_t list_entries_visited;  /* sum over step launches of L (all replicas) */
+} gd_timing;
+
+int gd_get_timing(gd_system *sys, gd_timing *out);
+/* Stream the handle enqueues on (hipStream_t as void*), for callers' own events. */
+int gd_get_stream(gd_system *sys, void **stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDYN_H */

@@ -1,0 +1,881 @@
+/* gdyn_oracle.c -- CPU fp64, single-thread restatement of the Brownian-dynamics path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (2022a-genome-dynamics_amd/) may
+ * link, load or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED.  The arithmetic of this path lives in snsinfu/micromd (<md.hpp>),
+ * an un-vendored git submodule of the reference (.gitmodules:10-12; pinned commit not
+ * recoverable, directory empty), and the reference has no tests, fixtures or golden
+ * vectors for it.  This file therefore restates micromd's
+ * published potential formulas and follows the reference's own call sites for the
+ * parameterisation and sequencing; it is pinned only by analytic known-answer tests,
+ * finite differences and the Random123 Philox known-answer vectors (tests/).
+ *
+ * It exports the same C-ABI as include/gdyn.h so the same test code drives both sides.
+ * Reference citations are relative to the reference root.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/gdyn.h"
+
+#define GD_NOISE_MT19937 3   /* oracle-only: std::mt19937_64 + polar normals, the reference's RNG class */
+#define MAX_BOND_TYPES 64
+#define MAX_POINT_SOURCES 4
+#define MAX_DYN 4
+
+static __thread char g_err[512];
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+const char *gd_last_error(void) { return g_err; }
+const char *gd_backend_name(void) { return "oracle"; }
+
+typedef struct {
+    int64_t step;
+    double time, bead_scale, bond_scale;
+    double semi[3], react[3];
+} ctx_t;
+
+typedef struct {
+    int used;
+    gd_bond_params p;
+    uint32_t n;
+    uint32_t *pairs;
+} dyn_t;
+
+typedef struct {
+    int kind;
+    double k, b, p[3];
+    uint8_t *mask; /* NULL = all beads */
+} psrc_t;
+
+struct gd_system {
+    uint32_t N, R;
+    int box_kind;
+    double box[3];
+    double *x; /* R*N*3 */
+    double *a, *b, *mob, *bend;
+    int has_pair;
+    gd_pair_softcore pair;
+    int nbt;
+    gd_bond_params bt[MAX_BOND_TYPES];
+    uint32_t nbonds, cap_bonds;
+    uint32_t *bi, *bj;
+    uint8_t *btype;
+    dyn_t dyn[MAX_DYN];
+    uint32_t ntrip, cap_trip;
+    uint32_t *ti;
+    double *te; /* >=0: constant energy; <0: per-bead (middle) */
+    int nps;
+    psrc_t ps[MAX_POINT_SOURCES];
+    int has_wall;
+    gd_wall wall;
+    int has_scaling;
+    double bs_init, bs_tau, bo_init, bo_tau;
+    ctx_t *ctx;
+    /* pair enumeration */
+    int brute;
+    double skin;
+    /* Verlet list per replica (rebuilt on demand) */
+    uint32_t **vl_start; /* [R][N+1] */
+    uint32_t **vl_idx;   /* [R][...] half list j>i */
+    double **vl_x0;      /* positions at build */
+    double *vl_rv;       /* list radius at build */
+    uint64_t rebuilds, visited;
+    gd_timing timing;
+};
+
+/* ----------------------------------------------------------------- utilities */
+
+static void *xcalloc(size_t n, size_t s)
+{
+    void *p = calloc(n ? n : 1, s);
+    if (!p) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
+    return p;
+}
+
+static inline double ipow(double x, int n)
+{
+    double r = 1;
+    while (n > 0) { if (n & 1) r *= x; x *= x; n >>= 1; }
+    return r;
+}
+
+static int valid_pq(int p, int q) { return (p == 2 || p == 4 || p == 6 || p == 8 || p == 12) && q >= 1 && q <= 4; }
+
+/* md::softcore_potential<P,Q>{energy,diameter}: U = eps (1-(r/sigma)^P)^Q, r<sigma
+ * (formula: micromd public documentation; call sites simulation_driver_forcefield.cc:35-44).
+ * Returns energy in *e and the radial factor fr such that F_on_i = fr * (x_i - x_j). */
+static inline void softcore_eval(double eps, double sigma, int P, int Q, double r2, double *e, double *fr)
+{
+    *e = 0; *fr = 0;
+    if (eps == 0 || sigma <= 0) return;
+    double s2 = sigma * sigma;
+    if (r2 >= s2) return;
+    double u2 = r2 / s2;
+    double uP = ipow(u2, P / 2);
+    double uPm2 = ipow(u2, P / 2 - 1);
+    double g = 1 - uP;
+    double gq1 = ipow(g, Q - 1);
+    *e = eps * gq1 * g;
+    *fr = eps * P * Q / s2 * gq1 * uPm2;
+}
+
+/* bonded pair potentials: harmonic / spring / semispring (micromd), see gdyn.h. */
+static inline void bond_eval(const gd_bond_params *p, double K, double l, double r2, double *e, double *fr)
+{
+    *e = 0; *fr = 0;
+    switch (p->kind) {
+    case GD_POT_HARMONIC:
+        *e = 0.5 * K * r2; *fr = -K; break;
+    case GD_POT_SPRING: {
+        double d = sqrt(r2);
+        *e = 0.5 * K * (d - l) * (d - l);
+        *fr = d > 0 ? -K * (d - l) / d : 0;
+        break; }
+    case GD_POT_SEMISPRING: {
+        double d = sqrt(r2);
+        if (d > l) { *e = 0.5 * K * (d - l) * (d - l); *fr = -K * (d - l) / d; }
+        break; }
+    case GD_POT_SOFTCORE:
+        softcore_eval(p->k_a, p->l_a, p->p, p->q, r2, e, fr); break;
+    }
+}
+
+static inline void min_image(const gd_system *s, double d[3])
+{
+    for (int k = 0; k < 3; k++) d[k] -= s->box[k] * nearbyint(d[k] / s->box[k]);
+}
+
+/* ------------------------------------------------------------ Philox4x32-10 */
+/* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11); the same
+ * generator, counter layout and uniform->normal map as the HIP kernels. */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+
+static inline double u01(uint32_t x) { return ((double)(x >> 9) + 0.5) * (1.0 / 8388608.0); }
+
+/* three standard normals for (bead, step, replica) under seed */
+static void philox_normal3(uint64_t seed, uint32_t bead, int64_t step, uint32_t replica, double z[3])
+{
+    uint32_t ctr[4] = { bead, (uint32_t)((uint64_t)step & 0xffffffffu), (uint32_t)((uint64_t)step >> 32), replica };
+    uint32_t key[2] = { (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32) };
+    uint32_t o[4];
+    philox4x32_10(ctr, key, o);
+    double r0 = sqrt(-2.0 * log(u01(o[0]))), t0 = 2.0 * M_PI * u01(o[1]);
+    double r1 = sqrt(-2.0 * log(u01(o[2]))), t1 = 2.0 * M_PI * u01(o[3]);
+    z[0] = r0 * cos(t0); z[1] = r0 * sin(t0); z[2] = r1 * cos(t1);
+}
+void oracle_philox_normal3(uint64_t seed, uint32_t bead, int64_t step, uint32_t replica, double z[3]) { philox_normal3(seed, bead, step, replica, z); }
+
+/* ------------------------------------------------------------- mt19937_64 */
+/* Matsumoto & Nishimura; the engine class the reference drivers use
+ * (simulation_interphase/simulation_driver.hpp:48). CPU-baseline noise only. */
+typedef struct { uint64_t mt[312]; int idx; int have; double spare; } mt64_t;
+static void mt64_seed(mt64_t *g, uint64_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 312; i++) g->mt[i] = 6364136223846793005ULL * (g->mt[i - 1] ^ (g->mt[i - 1] >> 62)) + (uint64_t)i;
+    g->idx = 312; g->have = 0;
+}
+static uint64_t mt64_next(mt64_t *g)
+{
+    if (g->idx >= 312) {
+        for (int i = 0; i < 312; i++) {
+            uint64_t x = (g->mt[i] & 0xFFFFFFFF80000000ULL) | (g->mt[(i + 1) % 312] & 0x7FFFFFFFULL);
+            g->mt[i] = g->mt[(i + 156) % 312] ^ (x >> 1) ^ ((x & 1) ? 0xB5026F5AA96619E9ULL : 0);
+        }
+        g->idx = 0;
+    }
+    uint64_t x = g->mt[g->idx++];
+    x ^= (x >> 29) & 0x5555555555555555ULL;
+    x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+    x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+    x ^= x >> 43;
+    return x;
+}
+uint64_t oracle_mt64_nth(uint64_t seed, int n) { mt64_t g; mt64_seed(&g, seed); uint64_t v = 0; for (int i = 0; i < n; i++) v = mt64_next(&g); return v; }
+static double mt64_normal(mt64_t *g)
+{
+    if (g->have) { g->have = 0; return g->spare; }
+    double x, y, r2;
+    do {
+        x = 2.0 * ((double)(mt64_next(g) >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+        y = 2.0 * ((double)(mt64_next(g) >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+        r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0.0);
+    double m = sqrt(-2.0 * log(r2) / r2);
+    g->spare = x * m; g->have = 1;
+    return y * m;
+}
+
+/* ------------------------------------------------------------------- system */
+
+int gd_create(const gd_desc *d, gd_system **out)
+{
+    if (!d || !out) return fail(GD_EINVAL, "gd_create: NULL argument");
+    if (d->n_beads == 0 || d->n_replicas == 0) return fail(GD_EINVAL, "gd_create: n_beads and n_replicas must be > 0");
+    if (d->box_kind != GD_BOX_OPEN && d->box_kind != GD_BOX_PERIODIC) return fail(GD_EINVAL, "gd_create: bad box_kind");
+    if (d->box_kind == GD_BOX_PERIODIC)
+        for (int k = 0; k < 3; k++) if (!(d->box[k] > 0)) return fail(GD_EINVAL, "gd_create: periodic box needs positive periods");
+    gd_system *s = xcalloc(1, sizeof *s);
+    s->N = d->n_beads; s->R = d->n_replicas; s->box_kind = d->box_kind;
+    memcpy(s->box, d->box, sizeof s->box);
+    size_t N = s->N, R = s->R;
+    s->x = xcalloc(R * N * 3, sizeof(double));
+    s->a = xcalloc(N, sizeof(double)); s->b = xcalloc(N, sizeof(double));
+    s->mob = xcalloc(N, sizeof(double)); s->bend = xcalloc(N, sizeof(double));
+    for (size_t i = 0; i < N; i++) s->mob[i] = 1.0;
+    s->ctx = xcalloc(R, sizeof(ctx_t));
+    for (size_t r = 0; r < R; r++) { s->ctx[r].bead_scale = 1; s->ctx[r].bond_scale = 1; }
+    s->skin = 0.3; s->brute = N <= 1024;
+    s->vl_start = xcalloc(R, sizeof(void *)); s->vl_idx = xcalloc(R, sizeof(void *));
+    s->vl_x0 = xcalloc(R, sizeof(void *)); s->vl_rv = xcalloc(R, sizeof(double));
+    *out = s;
+    return GD_OK;
+}
+
+int gd_destroy(gd_system *s)
+{
+    if (!s) return GD_OK;
+    for (uint32_t r = 0; r < s->R; r++) { free(s->vl_start[r]); free(s->vl_idx[r]); free(s->vl_x0[r]); }
+    free(s->vl_start); free(s->vl_idx); free(s->vl_x0); free(s->vl_rv);
+    for (int i = 0; i < MAX_DYN; i++) free(s->dyn[i].pairs);
+    for (int i = 0; i < s->nps; i++) free(s->ps[i].mask);
+    free(s->x); free(s->a); free(s->b); free(s->mob); free(s->bend);
+    free(s->bi); free(s->bj); free(s->btype); free(s->ti); free(s->te); free(s->ctx);
+    free(s);
+    return GD_OK;
+}
+
+void oracle_set_bruteforce(gd_system *s, int on) { s->brute = on; }
+
+static void invalidate_lists(gd_system *s)
+{
+    for (uint32_t r = 0; r < s->R; r++) { free(s->vl_start[r]); s->vl_start[r] = NULL; }
+}
+
+int gd_set_positions(gd_system *s, const double *xyz)
+{
+    if (!s || !xyz) return fail(GD_EINVAL, "gd_set_positions: NULL argument");
+    size_t n = (size_t)s->R * s->N * 3;
+    for (size_t i = 0; i < n; i++) if (!isfinite(xyz[i])) return fail(GD_EINVAL, "gd_set_positions: non-finite coordinate at %zu", i);
+    memcpy(s->x, xyz, n * sizeof(double));
+    invalidate_lists(s);
+    return GD_OK;
+}
+int gd_get_positions(gd_system *s, double *xyz)
+{
+    if (!s || !xyz) return fail(GD_EINVAL, "gd_get_positions: NULL argument");
+    memcpy(xyz, s->x, (size_t)s->R * s->N * 3 * sizeof(double));
+    return GD_OK;
+}
+int gd_get_positions_f32(gd_system *s, float *xyz, int quantize)
+{
+    if (!s || !xyz) return fail(GD_EINVAL, "gd_get_positions_f32: NULL argument");
+    size_t n = (size_t)s->R * s->N * 3;
+    for (size_t i = 0; i < n; i++) {
+        float v = (float)s->x[i];
+        /* simulation_common/simulation_store.cc:403-407: round(v * 65536) / 65536 in float */
+        if (quantize) v = nearbyintf(v * 65536.0f) / 65536.0f;
+        xyz[i] = v;
+    }
+    return GD_OK;
+}
+
+int gd_set_bead_params(gd_system *s, const double *a, const double *b, const double *mob, const double *bend)
+{
+    if (!s) return fail(GD_EINVAL, "gd_set_bead_params: NULL system");
+    size_t n = s->N * sizeof(double);
+    if (mob) for (uint32_t i = 0; i < s->N; i++) if (!(mob[i] >= 0)) return fail(GD_EINVAL, "gd_set_bead_params: negative mobility at %u", i);
+    if (a) memcpy(s->a, a, n);
+    if (b) memcpy(s->b, b, n);
+    if (mob) memcpy(s->mob, mob, n);
+    if (bend) memcpy(s->bend, bend, n);
+    return GD_OK;
+}
+
+int gd_set_pair_softcore(gd_system *s, const gd_pair_softcore *p)
+{
+    if (!s || !p) return fail(GD_EINVAL, "gd_set_pair_softcore: NULL argument");
+    if (!valid_pq(p->p_a, p->q_a) || !valid_pq(p->p_b, p->q_b)) return fail(GD_EINVAL, "gd_set_pair_softcore: unsupported softcore powers");
+    if (p->sigma_a < 0 || p->sigma_b < 0) return fail(GD_EINVAL, "gd_set_pair_softcore: negative diameter");
+    s->pair = *p; s->has_pair = 1;
+    invalidate_lists(s);
+    return GD_OK;
+}
+
+static int check_bond_params(const gd_bond_params *p)
+{
+    if (p->kind < GD_POT_HARMONIC || p->kind > GD_POT_SOFTCORE) return fail(GD_EINVAL, "bond params: bad kind %d", p->kind);
+    if (p->kind == GD_POT_SOFTCORE && !valid_pq(p->p, p->q)) return fail(GD_EINVAL, "bond params: unsupported softcore powers");
+    return GD_OK;
+}
+
+static int add_bond_type(gd_system *s, const gd_bond_params *p)
+{
+    for (int i = 0; i < s->nbt; i++) if (!memcmp(&s->bt[i], p, sizeof *p)) return i;
+    if (s->nbt >= MAX_BOND_TYPES) return -1;
+    s->bt[s->nbt] = *p;
+    return s->nbt++;
+}
+
+static void push_bond(gd_system *s, uint32_t i, uint32_t j, int t)
+{
+    if (s->nbonds == s->cap_bonds) {
+        s->cap_bonds = s->cap_bonds ? 2 * s->cap_bonds : 1024;
+        s->bi = realloc(s->bi, s->cap_bonds * sizeof(uint32_t));
+        s->bj = realloc(s->bj, s->cap_bonds * sizeof(uint32_t));
+        s->btype = realloc(s->btype, s->cap_bonds);
+    }
+    s->bi[s->nbonds] = i; s->bj[s->nbonds] = j; s->btype[s->nbonds] = (uint8_t)t; s->nbonds++;
+}
+
+int gd_add_bond_range(gd_system *s, const gd_bond_params *p, uint32_t start, uint32_t end, uint32_t stride)
+{
+    if (!s || !p) return fail(GD_EINVAL, "gd_add_bond_range: NULL argument");
+    int rc = check_bond_params(p); if (rc) return rc;
+    if (start > end || end > s->N) return fail(GD_EINVAL, "gd_add_bond_range: range [%u,%u) outside [0,%u)", start, end, s->N);
+    if (stride < 1 || stride > 2) return fail(GD_EINVAL, "gd_add_bond_range: stride must be 1 or 2");
+    int t = add_bond_type(s, p); if (t < 0) return fail(GD_EINVAL, "gd_add_bond_range: too many bond parameter sets");
+    for (uint32_t i = start; i + stride < end; i++) push_bond(s, i, i + stride, t);
+    return GD_OK;
+}
+
+int gd_add_bond_pairs(gd_system *s, const gd_bond_params *p, const uint32_t *pairs, uint32_t n)
+{
+    if (!s || !p || (n && !pairs)) return fail(GD_EINVAL, "gd_add_bond_pairs: NULL argument");
+    int rc = check_bond_params(p); if (rc) return rc;
+    for (uint32_t k = 0; k < n; k++)
+        if (pairs[2 * k] >= s->N || pairs[2 * k + 1] >= s->N || pairs[2 * k] == pairs[2 * k + 1])
+            return fail(GD_EINVAL, "gd_add_bond_pairs: bad pair %u (%u,%u)", k, pairs[2 * k], pairs[2 * k + 1]);
+    int t = add_bond_type(s, p); if (t < 0) return fail(GD_EINVAL, "gd_add_bond_pairs: too many bond parameter sets");
+    for (uint32_t k = 0; k < n; k++) push_bond(s, pairs[2 * k], pairs[2 * k + 1], t);
+    return GD_OK;
+}
+
+int gd_set_dynamic_pairs(gd_system *s, uint32_t slot, const gd_bond_params *p, const uint32_t *pairs, uint32_t n)
+{
+    if (!s || !p || (n && !pairs)) return fail(GD_EINVAL, "gd_set_dynamic_pairs: NULL argument");
+    if (slot >= MAX_DYN) return fail(GD_EINVAL, "gd_set_dynamic_pairs: slot %u out of range", slot);
+    int rc = check_bond_params(p); if (rc) return rc;
+    for (uint32_t k = 0; k < n; k++)
+        if (pairs[2 * k] >= s->N || pairs[2 * k + 1] >= s->N || pairs[2 * k] == pairs[2 * k + 1])
+            return fail(GD_EINVAL, "gd_set_dynamic_pairs: bad pair %u", k);
+    dyn_t *d = &s->dyn[slot];
+    free(d->pairs);
+    d->pairs = xcalloc(2 * (size_t)n, sizeof(uint32_t));
+    if (n) memcpy(d->pairs, pairs, 2 * (size_t)n * sizeof(uint32_t));
+    d->n = n; d->p = *p; d->used = 1;
+    return GD_OK;
+}
+
+int gd_add_bending_range(gd_system *s, uint32_t start, uint32_t end, double energy, int per_bead)
+{
+    if (!s) return fail(GD_EINVAL, "gd_add_bending_range: NULL system");
+    if (start > end || end > s->N) return fail(GD_EINVAL, "gd_add_bending_range: range outside [0,N)");
+    for (uint32_t i = start; i + 2 < end; i++) {
+        if (s->ntrip == s->cap_trip) {
+            s->cap_trip = s->cap_trip ? 2 * s->cap_trip : 1024;
+            s->ti = realloc(s->ti, s->cap_trip * sizeof(uint32_t));
+            s->te = realloc(s->te, s->cap_trip * sizeof(double));
+        }
+        s->ti[s->ntrip] = i; s->te[s->ntrip] = per_bead ? -1.0 : energy; s->ntrip++;
+    }
+    return GD_OK;
+}
+
+int gd_add_point_source(gd_system *s, int kind, double k, double b, const double point[3], const uint32_t *targets, uint32_t nt)
+{
+    if (!s || !point) return fail(GD_EINVAL, "gd_add_point_source: NULL argument");
+    if (kind != GD_POT_HARMONIC && kind != GD_POT_SEMISPRING && kind != GD_POT_SPRING) return fail(GD_EINVAL, "gd_add_point_source: unsupported kind");
+    if (s->nps >= MAX_POINT_SOURCES) return fail(GD_EINVAL, "gd_add_point_source: at most %d sources", MAX_POINT_SOURCES);
+    psrc_t *ps = &s->ps[s->nps];
+    ps->kind = kind; ps->k = k; ps->b = b; memcpy(ps->p, point, 3 * sizeof(double)); ps->mask = NULL;
+    if (targets) {
+        for (uint32_t i = 0; i < nt; i++) if (targets[i] >= s->N) return fail(GD_EINVAL, "gd_add_point_source: target %u out of range", targets[i]);
+        ps->mask = xcalloc(s->N, 1);
+        for (uint32_t i = 0; i < nt; i++) ps->mask[targets[i]] = 1;
+    }
+    s->nps++;
+    return GD_OK;
+}
+
+int gd_set_ellipsoid_wall(gd_system *s, const gd_wall *w)
+{
+    if (!s || !w) return fail(GD_EINVAL, "gd_set_ellipsoid_wall: NULL argument");
+    if (!valid_pq(w->p_a, w->q_a) || !valid_pq(w->p_b, w->q_b)) return fail(GD_EINVAL, "gd_set_ellipsoid_wall: unsupported softcore powers");
+    for (int k = 0; k < 3; k++) if (!(w->init_semiaxes[k] > 0)) return fail(GD_EINVAL, "gd_set_ellipsoid_wall: semiaxes must be positive");
+    s->wall = *w; s->has_wall = 1;
+    for (uint32_t r = 0; r < s->R; r++) memcpy(s->ctx[r].semi, w->init_semiaxes, sizeof s->ctx[r].semi);
+    return GD_OK;
+}
+
+int gd_set_scaling(gd_system *s, double bi, double bt, double oi, double ot)
+{
+    if (!s) return fail(GD_EINVAL, "gd_set_scaling: NULL system");
+    if (!(bt > 0) || !(ot > 0) || !(bi > 0) || !(oi > 0)) return fail(GD_EINVAL, "gd_set_scaling: init and tau must be positive");
+    s->has_scaling = 1; s->bs_init = bi; s->bs_tau = bt; s->bo_init = oi; s->bo_tau = ot;
+    for (uint32_t r = 0; r < s->R; r++) { s->ctx[r].bead_scale = bi; s->ctx[r].bond_scale = oi; }
+    invalidate_lists(s);
+    return GD_OK;
+}
+
+int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
+{
+    if (!s || !o) return fail(GD_EINVAL, "gd_get_context: NULL argument");
+    if (r >= s->R) return fail(GD_EINVAL, "gd_get_context: replica out of range");
+    memset(o, 0, sizeof *o);
+    ctx_t *c = &s->ctx[r];
+    o->step = c->step; o->time = c->time; o->bead_scale = c->bead_scale; o->bond_scale = c->bond_scale;
+    memcpy(o->semiaxes, c->semi, sizeof c->semi); memcpy(o->axial_reaction, c->react, sizeof c->react);
+    o->rebuilds = s->rebuilds;
+    if (s->vl_start[r]) { o->list_entries = 2ull * s->vl_start[r][s->N]; o->list_radius = s->vl_rv[r]; }
+    return GD_OK;
+}
+
+int gd_begin_phase(gd_system *s, const double *semi)
+{
+    if (!s) return fail(GD_EINVAL, "gd_begin_phase: NULL system");
+    for (uint32_t r = 0; r < s->R; r++) {
+        ctx_t *c = &s->ctx[r];
+        c->step = 0; c->time = 0;
+        if (s->has_scaling) { c->bead_scale = s->bs_init; c->bond_scale = s->bo_init; }
+        if (semi) memcpy(c->semi, semi + 3 * r, sizeof c->semi);
+    }
+    invalidate_lists(s);
+    return GD_OK;
+}
+
+int gd_set_context(gd_system *s, uint32_t r, int64_t step, double bead_scale, double bond_scale, const double semi[3])
+{
+    if (!s) return fail(GD_EINVAL, "gd_set_context: NULL system");
+    if (r >= s->R) return fail(GD_EINVAL, "gd_set_context: replica out of range");
+    if (!(bead_scale > 0) || !(bond_scale > 0)) return fail(GD_EINVAL, "gd_set_context: scales must be positive");
+    ctx_t *c = &s->ctx[r];
+    c->step = step; c->bead_scale = bead_scale; c->bond_scale = bond_scale;
+    if (semi) memcpy(c->semi, semi, sizeof c->semi);
+    free(s->vl_start[r]); s->vl_start[r] = NULL;
+    return GD_OK;
+}
+
+int gd_set_tuning(gd_system *s, const gd_tuning *t)
+{
+    if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
+    if (t->skin > 0) s->skin = t->skin;
+    invalidate_lists(s);
+    return GD_OK;
+}
+int gd_get_timing(gd_system *s, gd_timing *o) { if (!s || !o) return fail(GD_EINVAL, "gd_get_timing: NULL"); *o = s->timing; return GD_OK; }
+int gd_get_stream(gd_system *s, void **st) { (void)s; if (st) *st = NULL; return GD_OK; }
+
+/* --------------------------------------------------------------- cell grid */
+
+typedef struct {
+    int nc[3];
+    double org[3], inv[3];
+    uint32_t *start, *items;
+} grid_t;
+
+static inline int cell_coord(const gd_system *s, const grid_t *g, double v, int k)
+{
+    if (s->box_kind == GD_BOX_PERIODIC) {
+        double f = v / s->box[k]; f -= floor(f);
+        int c = (int)(f * g->nc[k]);
+        return c >= g->nc[k] ? g->nc[k] - 1 : c;
+    }
+    int c = (int)floor((v - g->org[k]) * g->inv[k]);
+    return c < 0 ? 0 : (c >= g->nc[k] ? g->nc[k] - 1 : c);
+}
+
+static void grid_build(const gd_system *s, const double *x, double rc, grid_t *g)
+{
+    uint32_t N = s->N;
+    double lo[3], hi[3];
+    if (s->box_kind == GD_BOX_PERIODIC) {
+        for (int k = 0; k < 3; k++) {
+            int n = (int)floor(s->box[k] / rc); if (n < 1) n = 1; if (n > 256) n = 256;
+            g->nc[k] = n; g->org[k] = 0; g->inv[k] = n / s->box[k];
+        }
+    } else {
+        for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        for (uint32_t i = 0; i < N; i++) for (int k = 0; k < 3; k++) { double v = x[3 * i + k]; if (v < lo[k]) lo[k] = v; if (v > hi[k]) hi[k] = v; }
+        for (int k = 0; k < 3; k++) {
+            double ext = hi[k] - lo[k]; if (!(ext > 0)) ext = rc;
+            int n = (int)floor(ext / rc) + 1; if (n > 256) n = 256;
+            double cs = ext / n; if (cs < rc) cs = rc;
+            g->nc[k] = n; g->org[k] = lo[k]; g->inv[k] = 1.0 / cs;
+        }
+    }
+    size_t nc = (size_t)g->nc[0] * g->nc[1] * g->nc[2];
+    g->start = xcalloc(nc + 1, sizeof(uint32_t)); g->items = xcalloc(N, sizeof(uint32_t));
+    uint32_t *cid = xcalloc(N, sizeof(uint32_t));
+    for (uint32_t i = 0; i < N; i++) {
+        int c0 = cell_coord(s, g, x[3 * i], 0), c1 = cell_coord(s, g, x[3 * i + 1], 1), c2 = cell_coord(s, g, x[3 * i + 2], 2);
+        cid[i] = (uint32_t)((c2 * g->nc[1] + c1) * g->nc[0] + c0);
+        g->start[cid[i] + 1]++;
+    }
+    for (size_t c = 0; c < nc; c++) g->start[c + 1] += g->start[c];
+    uint32_t *fill = xcalloc(nc, sizeof(uint32_t));
+    for (uint32_t i = 0; i < N; i++) g->items[g->start[cid[i]] + fill[cid[i]]++] = i;
+    free(fill); free(cid);
+}
+static void grid_free(grid_t *g) { free(g->start); free(g->items); }
+
+/* Enumerate all unordered pairs within rc: cb(i,j) with i<j. Spatial hashing into cells
+ * >= rc and a 27-cell sweep, as md::neighbor_searcher does (contact_map.cc:64-66). */
+typedef void (*pair_cb)(void *ud, uint32_t i, uint32_t j);
+
+static void enum_pairs(const gd_system *s, const double *x, double rc, pair_cb cb, void *ud)
+{
+    uint32_t N = s->N;
+    double rc2 = rc * rc;
+    if (s->brute) {
+        for (uint32_t i = 0; i < N; i++) for (uint32_t j = i + 1; j < N; j++) {
+            double d[3] = { x[3 * i] - x[3 * j], x[3 * i + 1] - x[3 * j + 1], x[3 * i + 2] - x[3 * j + 2] };
+            if (s->box_kind == GD_BOX_PERIODIC) min_image(s, d);
+            if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) cb(ud, i, j);
+        }
+        return;
+    }
+    grid_t g; grid_build(s, x, rc, &g);
+    int per = s->box_kind == GD_BOX_PERIODIC;
+    for (int cz = 0; cz < g.nc[2]; cz++) for (int cy = 0; cy < g.nc[1]; cy++) for (int cx = 0; cx < g.nc[0]; cx++) {
+        uint32_t c = (uint32_t)((cz * g.nc[1] + cy) * g.nc[0] + cx);
+        /* visit distinct neighbour cells once (small periodic grids alias) */
+        uint32_t seen[27]; int ns = 0;
+        for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+            int nx = cx + dx, ny = cy + dy, nz = cz + dz;
+            if (per) { nx = (nx + g.nc[0]) % g.nc[0]; ny = (ny + g.nc[1]) % g.nc[1]; nz = (nz + g.nc[2]) % g.nc[2]; }
+            else if (nx < 0 || ny < 0 || nz < 0 || nx >= g.nc[0] || ny >= g.nc[1] || nz >= g.nc[2]) continue;
+            uint32_t c2 = (uint32_t)((nz * g.nc[1] + ny) * g.nc[0] + nx);
+            if (c2 < c) continue;
+            int dup = 0; for (int q = 0; q < ns; q++) if (seen[q] == c2) dup = 1;
+            if (dup) continue;
+            seen[ns++] = c2;
+            for (uint32_t p = g.start[c]; p < g.start[c + 1]; p++) {
+                uint32_t i = g.items[p];
+                for (uint32_t q = (c2 == c ? p + 1 : g.start[c2]); q < g.start[c2 + 1]; q++) {
+                    uint32_t j = g.items[q];
+                    double d[3] = { x[3 * i] - x[3 * j], x[3 * i + 1] - x[3 * j + 1], x[3 * i + 2] - x[3 * j + 2] };
+                    if (per) min_image(s, d);
+                    if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) { if (i < j) cb(ud, i, j); else cb(ud, j, i); }
+                }
+            }
+        }
+    }
+    grid_free(&g);
+}
+
+typedef struct { uint32_t *pairs; uint64_t cap, n; } collect_t;
+static void collect_cb(void *ud, uint32_t i, uint32_t j)
+{
+    collect_t *c = ud;
+    if (c->n < c->cap) { c->pairs[2 * c->n] = i; c->pairs[2 * c->n + 1] = j; }
+    c->n++;
+}
+
+int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *pairs, uint64_t cap, uint64_t *n_pairs)
+{
+    if (!s || !n_pairs || (cap && !pairs)) return fail(GD_EINVAL, "gd_search_pairs: NULL argument");
+    if (r >= s->R || !(dcut > 0)) return fail(GD_EINVAL, "gd_search_pairs: bad replica or cutoff");
+    collect_t c = { pairs, cap, 0 };
+    enum_pairs(s, s->x + (size_t)r * s->N * 3, dcut, collect_cb, &c);
+    *n_pairs = c.n;
+    return GD_OK;
+}
+
+/* ------------------------------------------------------------- Verlet list */
+
+typedef struct { uint32_t *cnt; uint32_t *start; uint32_t *idx; int pass; } vl_build_t;
+static void vl_cb(void *ud, uint32_t i, uint32_t j)
+{
+    vl_build_t *b = ud;
+    if (b->pass == 0) b->cnt[i]++;
+    else b->idx[b->start[i] + b->cnt[i]++] = j;
+}
+
+static double pair_cutoff(const gd_system *s, const ctx_t *c)
+{
+    double m = 0;
+    if (s->pair.eps_a != 0 && s->pair.sigma_a > m) m = s->pair.sigma_a;
+    if (s->pair.eps_b != 0 && s->pair.sigma_b > m) m = s->pair.sigma_b;
+    return s->pair.scale_by_bead_scale ? m * c->bead_scale : m;
+}
+
+static void vl_ensure(gd_system *s, uint32_t r, double cutoff)
+{
+    uint32_t N = s->N;
+    const double *x = s->x + (size_t)r * N * 3;
+    if (s->vl_start[r]) {
+        double lim = 0.5 * (s->vl_rv[r] - cutoff), lim2 = lim * lim;
+        int ok = lim > 0;
+        const double *x0 = s->vl_x0[r];
+        for (uint32_t i = 0; ok && i < N; i++) {
+            double d0 = x[3 * i] - x0[3 * i], d1 = x[3 * i + 1] - x0[3 * i + 1], d2 = x[3 * i + 2] - x0[3 * i + 2];
+            if (d0 * d0 + d1 * d1 + d2 * d2 > lim2) ok = 0;
+        }
+        if (ok) return;
+        free(s->vl_start[r]); free(s->vl_idx[r]); free(s->vl_x0[r]);
+    }
+    double rv = cutoff * (1 + s->skin);
+    vl_build_t b; b.cnt = xcalloc(N, sizeof(uint32_t)); b.start = xcalloc(N + 1, sizeof(uint32_t)); b.idx = NULL; b.pass = 0;
+    enum_pairs(s, x, rv, vl_cb, &b);
+    for (uint32_t i = 0; i < N; i++) b.start[i + 1] = b.start[i] + b.cnt[i];
+    b.idx = xcalloc(b.start[N], sizeof(uint32_t));
+    memset(b.cnt, 0, N * sizeof(uint32_t)); b.pass = 1;
+    enum_pairs(s, x, rv, vl_cb, &b);
+    free(b.cnt);
+    s->vl_start[r] = b.start; s->vl_idx[r] = b.idx; s->vl_rv[r] = rv;
+    s->vl_x0[r] = xcalloc((size_t)N * 3, sizeof(double));
+    memcpy(s->vl_x0[r], x, (size_t)N * 3 * sizeof(double));
+    s->rebuilds++;
+}
+
+/* ------------------------------------------------------------------ forces */
+
+typedef struct {
+    const gd_system *s; const double *x; double *F; double E; double sc; int want_e; int per;
+} pair_ctx_t;
+
+static inline void pair_apply(pair_ctx_t *pc, uint32_t i, uint32_t j)
+{
+    const gd_system *s = pc->s; const double *x = pc->x;
+    double d[3] = { x[3 * i] - x[3 * j], x[3 * i + 1] - x[3 * j + 1], x[3 * i + 2] - x[3 * j + 2] };
+    if (pc->per) min_image(s, d);
+    double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const gd_pair_softcore *p = &s->pair;
+    double wa = 1, wb = 1;
+    if (p->mix) { wa = 0.5 * (s->a[i] + s->a[j]); wb = 0.5 * (s->b[i] + s->b[j]); }
+    double ea, fa, eb, fb;
+    softcore_eval(p->eps_a, p->sigma_a * pc->sc, p->p_a, p->q_a, r2, &ea, &fa);
+    softcore_eval(p->eps_b, p->sigma_b * pc->sc, p->p_b, p->q_b, r2, &eb, &fb);
+    double f = wa * fa + wb * fb;
+    if (pc->F) for (int k = 0; k < 3; k++) { pc->F[3 * i + k] += f * d[k]; pc->F[3 * j + k] -= f * d[k]; }
+    pc->E += wa * ea + wb * eb;
+}
+static void pair_cb_apply(void *ud, uint32_t i, uint32_t j) { pair_apply(ud, i, j); }
+
+static void eval_bond(const gd_system *s, const ctx_t *c, const gd_bond_params *p, uint32_t i, uint32_t j,
+                      const double *x, double *F, double *E)
+{
+    double d[3] = { x[3 * i] - x[3 * j], x[3 * i + 1] - x[3 * j + 1], x[3 * i + 2] - x[3 * j + 2] };
+    if (p->minimum_image && s->box_kind == GD_BOX_PERIODIC) min_image(s, d);
+    double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    double K = p->k_a, l = p->l_a;
+    if (p->mix) {
+        double a = 0.5 * (s->a[i] + s->a[j]), b = 0.5 * (s->b[i] + s->b[j]);
+        K = a * p->k_a + b * p->k_b; l = a * p->l_a + b * p->l_b;
+    }
+    if (p->scale_by_bond_scale) { double sc = c->bond_scale; K = K * (1 / (sc * sc)); l = l * sc; }
+    double e, fr;
+    bond_eval(p, K, l, r2, &e, &fr);
+    if (F) for (int k = 0; k < 3; k++) { F[3 * i + k] += fr * d[k]; F[3 * j + k] -= fr * d[k]; }
+    *E += e;
+}
+
+/* Ellipsoid wall. Nearest-surface displacement by the second-order construction the
+ * reference author uses in 5-sim-genome/src/analyze_lamina/geometry.py:13-28: intersect
+ * the line through p along grad f(p) with the surface; delta = p - q. Exact for a sphere.
+ * axial_reaction_k = sum_i (-F_i,k) q_i,k / a_k (virtual work of the wall's contact force
+ * under a change of semiaxis k): a documented choice, micromd's definition is not
+ * recoverable. */
+static int wall_delta(const double p[3], const double semi[3], double delta[3], double q[3], double *C)
+{
+    double s1[3], A = 0, B = 0, c = -1;
+    for (int k = 0; k < 3; k++) {
+        double i2 = 1.0 / (semi[k] * semi[k]);
+        s1[k] = p[k] * i2;
+        c += p[k] * s1[k]; B += s1[k] * s1[k]; A += s1[k] * s1[k] * i2;
+    }
+    *C = c;
+    if (!(A > 0)) return 0; /* bead exactly at the centre: infinitely far from the wall */
+    double disc = B * B - A * c;
+    if (disc < 0) disc = 0;
+    double u = (B - sqrt(disc)) / A;
+    for (int k = 0; k < 3; k++) { delta[k] = u * s1[k]; q[k] = p[k] - delta[k]; }
+    return 1;
+}
+
+static double compute(gd_system *s, uint32_t r, uint32_t mask, double *F, int want_e)
+{
+    uint32_t N = s->N;
+    const double *x = s->x + (size_t)r * N * 3;
+    ctx_t *c = &s->ctx[r];
+    double E = 0;
+    if (F) memset(F, 0, (size_t)N * 3 * sizeof(double));
+    (void)want_e;
+
+    if ((mask & GD_TERM_PAIR) && s->has_pair) {
+        double sc = s->pair.scale_by_bead_scale ? c->bead_scale : 1.0;
+        double cutoff = pair_cutoff(s, c);
+        pair_ctx_t pc = { s, x, F, 0, sc, 1, s->box_kind == GD_BOX_PERIODIC };
+        if (cutoff > 0) {
+            if (s->brute) enum_pairs(s, x, cutoff, pair_cb_apply, &pc);
+            else {
+                vl_ensure(s, r, cutoff);
+                const uint32_t *st = s->vl_start[r], *ix = s->vl_idx[r];
+                double c2 = cutoff * cutoff;
+                for (uint32_t i = 0; i < N; i++) for (uint32_t q = st[i]; q < st[i + 1]; q++) {
+                    uint32_t j = ix[q];
+                    double d[3] = { x[3 * i] - x[3 * j], x[3 * i + 1] - x[3 * j + 1], x[3 * i + 2] - x[3 * j + 2] };
+                    if (pc.per) min_image(s, d);
+                    if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < c2) pair_apply(&pc, i, j);
+                }
+                s->visited += 2ull * st[N];
+            }
+        }
+        E += pc.E;
+    }
+    if (mask & GD_TERM_BOND)
+        for (uint32_t k = 0; k < s->nbonds; k++) eval_bond(s, c, &s->bt[s->btype[k]], s->bi[k], s->bj[k], x, F, &E);
+    if (mask & GD_TERM_DYNAMIC)
+        for (int d = 0; d < MAX_DYN; d++) if (s->dyn[d].used)
+            for (uint32_t k = 0; k < s->dyn[d].n; k++) eval_bond(s, c, &s->dyn[d].p, s->dyn[d].pairs[2 * k], s->dyn[d].pairs[2 * k + 1], x, F, &E);
+    if (mask & GD_TERM_BEND)
+        for (uint32_t t = 0; t < s->ntrip; t++) {
+            /* md::cosine_bending_potential: U = e (1 - cos theta), cos theta = d1.d2/|d1||d2|,
+             * d1 = x_j - x_i, d2 = x_k - x_j (zero for a straight chain). */
+            uint32_t i = s->ti[t], j = i + 1, k = i + 2;
+            double e = s->te[t] < 0 ? s->bend[j] : s->te[t];
+            if (e == 0) continue;
+            double d1[3], d2[3], n1 = 0, n2 = 0, dot = 0;
+            for (int q = 0; q < 3; q++) { d1[q] = x[3 * j + q] - x[3 * i + q]; d2[q] = x[3 * k + q] - x[3 * j + q]; n1 += d1[q] * d1[q]; n2 += d2[q] * d2[q]; dot += d1[q] * d2[q]; }
+            if (n1 == 0 || n2 == 0) continue;
+            double l1 = sqrt(n1), l2 = sqrt(n2), cs = dot / (l1 * l2);
+            E += e * (1 - cs);
+            if (F) for (int q = 0; q < 3; q++) {
+                double g1 = (d2[q] / l2 - cs * d1[q] / l1) / l1; /* d cos / d d1 */
+                double g2 = (d1[q] / l1 - cs * d2[q] / l2) / l2; /* d cos / d d2 */
+                double fi = -e * g1, fk = e * g2;
+                F[3 * i + q] += fi; F[3 * k + q] += fk; F[3 * j + q] -= fi + fk;
+            }
+        }
+    if (mask & GD_TERM_POINT)
+        for (int p = 0; p < s->nps; p++) {
+            const psrc_t *ps = &s->ps[p];
+            gd_bond_params bp; memset(&bp, 0, sizeof bp); bp.kind = ps->kind;
+            for (uint32_t i = 0; i < N; i++) {
+                if (ps->mask && !ps->mask[i]) continue;
+                double d[3] = { x[3 * i] - ps->p[0], x[3 * i + 1] - ps->p[1], x[3 * i + 2] - ps->p[2] };
+                double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], e, fr;
+                bond_eval(&bp, ps->k, ps->b, r2, &e, &fr);
+                E += e;
+                if (F) for (int k = 0; k < 3; k++) F[3 * i + k] += fr * d[k];
+            }
+        }
+    if ((mask & GD_TERM_WALL) && s->has_wall) {
+        const gd_wall *w = &s->wall;
+        double sc = w->scale_by_bead_scale ? c->bead_scale : 1.0;
+        double react[3] = { 0, 0, 0 };
+        for (uint32_t i = 0; i < N; i++) {
+            double delta[3], q[3], C;
+            if (!wall_delta(x + 3 * i, c->semi, delta, q, &C)) continue;
+            double r2 = delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2], e = 0, fr = 0;
+            if (C < 0) { /* inside: inward soft wall, half diameters */
+                double wa = 0.5 * (s->a[i] + w->wall_a_factor), wb = 0.5 * (s->b[i] + w->wall_b_factor), ea, fa, eb, fb;
+                softcore_eval(w->eps_a, 0.5 * w->sigma_a * sc, w->p_a, w->q_a, r2, &ea, &fa);
+                softcore_eval(w->eps_b, 0.5 * w->sigma_b * sc, w->p_b, w->q_b, r2, &eb, &fb);
+                e = wa * ea + wb * eb; fr = wa * fa + wb * fb;
+            } else if (C > 0) { /* outside: harmonic restoring force */
+                e = 0.5 * w->packing_spring * r2; fr = -w->packing_spring;
+            }
+            E += e;
+            if (fr != 0) for (int k = 0; k < 3; k++) {
+                double f = fr * delta[k];
+                if (F) F[3 * i + k] += f;
+                react[k] += -f * q[k] / c->semi[k];
+            }
+        }
+        if (F) memcpy(c->react, react, sizeof react);
+    }
+    return E;
+}
+
+int gd_compute_energy(gd_system *s, uint32_t mask, double *energy)
+{
+    if (!s || !energy) return fail(GD_EINVAL, "gd_compute_energy: NULL argument");
+    for (uint32_t r = 0; r < s->R; r++) energy[r] = compute(s, r, mask, NULL, 1);
+    return GD_OK;
+}
+
+int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
+{
+    if (!s || !forces) return fail(GD_EINVAL, "gd_compute_forces: NULL argument");
+    for (uint32_t r = 0; r < s->R; r++) compute(s, r, mask, forces + (size_t)r * s->N * 3, 0);
+    return GD_OK;
+}
+
+/* ---------------------------------------------------------------- stepping */
+
+/* md::simulate_brownian_dynamics (call site simulation_driver_interphase.cc:48-55):
+ * Euler-Maruyama, callback(k) after the position update of step k. */
+int gd_run(gd_system *s, const gd_run_desc *run)
+{
+    if (!s || !run) return fail(GD_EINVAL, "gd_run: NULL argument");
+    if (run->spacestep != 0) return fail(GD_EUNSUPPORTED, "gd_run: spacestep != 0 (adaptive timestep) is not supported");
+    if (run->steps < 0 || !(run->timestep > 0) || run->temperature < 0) return fail(GD_EINVAL, "gd_run: bad steps/timestep/temperature");
+    if (run->noise_mode < 0 || run->noise_mode > GD_NOISE_MT19937) return fail(GD_EINVAL, "gd_run: bad noise_mode");
+    if (run->noise_mode == GD_NOISE_HOST && !run->host_noise) return fail(GD_EINVAL, "gd_run: host noise requested without array");
+    if ((run->flags & GD_RUN_WALL_DYNAMICS) && !s->has_wall) return fail(GD_ESTATE, "gd_run: wall dynamics requested without a wall");
+    if ((run->flags & GD_RUN_UPDATE_SCALES) && !s->has_scaling) return fail(GD_ESTATE, "gd_run: scale updates requested without gd_set_scaling");
+    uint32_t N = s->N, R = s->R;
+    double dt = run->timestep, kT = run->temperature;
+    double *F = xcalloc((size_t)N * 3, sizeof(double));
+    mt64_t *mt = NULL;
+    if (run->noise_mode == GD_NOISE_MT19937) { mt = xcalloc(R, sizeof *mt); for (uint32_t r = 0; r < R; r++) mt64_seed(&mt[r], run->seed + r); }
+    for (int64_t k = 1; k <= run->steps; k++) {
+        for (uint32_t r = 0; r < R; r++) {
+            ctx_t *c = &s->ctx[r];
+            double *x = s->x + (size_t)r * N * 3;
+            memset(c->react, 0, sizeof c->react);
+            compute(s, r, GD_TERM_ALL, F, 0);
+            int64_t gstep = c->step + 1;
+            for (uint32_t i = 0; i < N; i++) {
+                double mu_dt = s->mob[i] * dt, z[3] = { 0, 0, 0 };
+                if (kT > 0) switch (run->noise_mode) {
+                    case GD_NOISE_PHILOX: philox_normal3(run->seed, i, gstep, r, z); break;
+                    case GD_NOISE_HOST: { const double *h = run->host_noise + (((size_t)(k - 1) * R + r) * N + i) * 3; z[0] = h[0]; z[1] = h[1]; z[2] = h[2]; break; }
+                    case GD_NOISE_MT19937: z[0] = mt64_normal(&mt[r]); z[1] = mt64_normal(&mt[r]); z[2] = mt64_normal(&mt[r]); break;
+                    default: break;
+                }
+                double sg = sqrt(2 * kT * mu_dt);
+                for (int q = 0; q < 3; q++) x[3 * i + q] += mu_dt * F[3 * i + q] + sg * z[q];
+            }
+            /* callback(gstep): simulation_driver_interphase.cc:12-44 */
+            c->step = gstep; c->time = (double)gstep * dt;
+            if (run->flags & GD_RUN_UPDATE_SCALES) {
+                c->bead_scale = 1 - (1 - s->bs_init) * exp(-c->time / s->bs_tau);
+                c->bond_scale = 1 - (1 - s->bo_init) * exp(-c->time / s->bo_tau);
+            }
+            if (run->flags & GD_RUN_WALL_DYNAMICS)
+                for (int q = 0; q < 3; q++)
+                    c->semi[q] += dt * s->wall.mobility * (c->react[q] - s->wall.semiaxes_spring[q] * c->semi[q]);
+        }
+    }
+    free(F); free(mt);
+    s->timing.list_entries_visited = s->visited;
+    return GD_OK;
+}

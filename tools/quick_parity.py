@@ -1,0 +1,40 @@
+"""Quick GPU-vs-oracle parity probe (developer tool; the real checks are in tests/)."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+g = importlib.import_module("2022a-genome-dynamics_amd")
+wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
+hip = g.load()
+orc = g.Lib(os.path.join(ROOT, "oracle", "liboracle.so"))
+
+def cmp(name, a, b):
+    d = np.abs(a - b).max(); s = np.abs(b).max()
+    print(f"  {name}: max|diff| {d:.3e}  max|ref| {s:.3e}  rel {d/(s+1e-300):.2e}")
+
+def probe(builder, steps, dt, kT, flags=0, **kw):
+    print(builder.__name__, kw)
+    sh, info = builder(hip, **kw); so, _ = builder(orc, **kw)
+    for t, nm in ((1, "pair"), (2, "bond"), (4, "bend"), (8, "point"), (16, "wall"), (32, "dyn"), (63, "all")):
+        fo = so.forces(t)
+        if np.abs(fo).max() == 0: continue
+        cmp("F " + nm, sh.forces(t), fo)
+        cmp("E " + nm, sh.energy(t), so.energy(t))
+    for mode, nm in ((g.NOISE_ZERO, "T0"), (g.NOISE_PHILOX, "philox")):
+        sh.set_positions(so.positions()); 
+        x0 = so.positions()
+        sh.begin_phase(); so.begin_phase()
+        t0 = time.time(); sh.run(steps, dt, kT, seed=7, noise=mode, flags=flags); t1 = time.time()
+        so.run(steps, dt, kT, seed=7, noise=mode, flags=flags)
+        cmp(f"x after {steps} steps {nm}", sh.positions(), so.positions())
+        ch, co = sh.context(), so.context()
+        print("   ctx hip", ch.step, ch.time, list(ch.semiaxes), ch.bead_scale, "K", ch.rebuild_interval, "L", ch.list_entries, "rb", ch.rebuilds, "roll", ch.rollbacks)
+        print("   ctx orc", co.step, co.time, list(co.semiaxes), co.bead_scale)
+        so.set_positions(x0)
+    return sh, so
+
+probe(wl.genome_interphase, 20, 1e-5, 1.0, flags=3, n_beads=2000, bead_scale_init=0.8)
+probe(wl.spindle, 20, 1e-4, 0.1, n_beads=300)
+probe(wl.ab_box, 20, 1e-5, 1.0)
+probe(wl.chromatin_1kb, 20, 1e-4, 1.0, n_beads=4000, n_loops=40, n_glues=80)
+probe(wl.genome_interphase, 5, 1e-5, 1.0, flags=3, n_beads=3000, n_replicas=3)
