@@ -9,12 +9,15 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/gdyn.h"
+#include <hip/hip_fp16.h>
+
 #include "gdyn_types.h"
 
 // ------------------------------------------------------------------ errors
@@ -89,6 +92,9 @@ struct gd_system {
     bool has_bend = false, has_bonds = false;
     uint32_t WB = 0, W = 0, ncell_cap = 0;
     int pcur = 0, ccur = 0;
+    uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
+    bool packed_ab = false, tiled_ok = true, list_tiled = false;
+    uint32_t cpb = 1, tile_cap = 3072;
 
     // tuning / cadence
     double skin = 0.5;
@@ -104,7 +110,8 @@ struct gd_system {
     DevBuf<unsigned> badj_o; DevBuf<int4> chain_o; DevBuf<BondType> btab;
     // device: per slot
     DevBuf<float4> pos[2], xb, fout, snap;
-    DevBuf<unsigned> orig[2], slot_of, cell_id, rank, cell_cnt, cell_start, nbr, ncnt, badj, flags;
+    DevBuf<unsigned> orig[2], slot_of, cell_id, rank, cell_cnt, cell_start, nbr, ncnt, badj, flags, cell_s;
+    DevBuf<unsigned short> nbr16; DevBuf<TileDesc> tiles;
     DevBuf<float> bbox;
     DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<unsigned char> psmask, bdeg; DevBuf<int4> chain;
     DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part; DevBuf<double> epart;
@@ -139,6 +146,7 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     memcpy(s->box, d->box, sizeof s->box);
     s->nblk = (s->N + GD_BLOCK - 1) / GD_BLOCK;
     s->Np = s->nblk * GD_BLOCK;
+    s->cpb = (s->nblk + GD_XCDS - 1) / GD_XCDS;
     s->a.assign(s->N, 0.0); s->b.assign(s->N, 0.0); s->mob.assign(s->N, 1.0); s->bend.assign(s->N, 0.0);
     s->hctx.assign(s->R, DevCtx{});
     for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; c.semi[0] = c.semi[1] = c.semi[2] = 1; }
@@ -158,7 +166,8 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->bendE.resize(RNp) == hipSuccess &&
          s->psmask.resize(RNp) == hipSuccess && s->bdeg.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->react_part.resize((size_t)s->R * s->nblk) == hipSuccess && s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
-         s->lcount_d.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess;
+         s->lcount_d.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
+         s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess;
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
     gd_launch_identity(s->orig[0].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     if (hipStreamSynchronize(s->stream) != hipSuccess) { delete s; return fail(GD_EHIP, "gd_create: identity kernel failed"); }
@@ -412,6 +421,8 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     s->adapt = t->adapt_interval;
     if (t->list_width > 0 && t->list_width != s->W) { s->W = 0; s->nbr.resize(0); s->W = t->list_width; }
     s->use_graph = t->use_graph;
+    if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0, 1 or 2");
+    s->kernel_path = t->kernel_path; s->tiled_ok = true;
     s->list_valid = false;
     return GD_OK;
 }
@@ -486,7 +497,13 @@ static int finalize_topology(gd_system *s)
         for (uint32_t i = 0; i < N; i++) if (s->psrc[q].mask.empty() || s->psrc[q].mask[i]) psm[i] |= (unsigned char)(1u << q);
     std::vector<float2> ab(N);
     std::vector<float> mob(N);
-    for (uint32_t i = 0; i < N; i++) { ab[i] = make_float2((float)s->a[i], (float)s->b[i]); mob[i] = (float)s->mob[i]; }
+    bool packable = true;
+    for (uint32_t i = 0; i < N; i++) {
+        ab[i] = make_float2((float)s->a[i], (float)s->b[i]); mob[i] = (float)s->mob[i];
+        // (a,b) ride in pos.w as two fp16 when that is exact (0, .5, 1, 5 ... are)
+        if ((double)__half2float(__float2half_rn(ab[i].x)) != s->a[i] || (double)__half2float(__float2half_rn(ab[i].y)) != s->b[i]) packable = false;
+    }
+    s->packed_ab = packable;
 
     HIPCHK(s->ab_o.resize(N)); HIPCHK(s->mob_o.resize(N)); HIPCHK(s->bendE_o.resize(N)); HIPCHK(s->psmask_o.resize(N));
     HIPCHK(s->bdeg_o.resize(N)); HIPCHK(s->badj_o.resize(adj.size())); HIPCHK(s->chain_o.resize(N)); HIPCHK(s->btab.resize(bt.size()));
@@ -530,7 +547,10 @@ static void fill_common(gd_system *s, StepParams &p)
     for (int k = 0; k < 3; k++) { p.box[k] = (float)s->box[k]; p.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
     p.pos_in = s->pos[s->pcur].p; p.pos_out = s->pos[s->pcur ^ 1].p; p.xb = s->xb.p; p.orig = s->orig[s->ocur].p;
     p.ab = s->ab.p; p.mob = s->mobs.p; p.bendE = s->bendE.p; p.psmask = s->psmask.p;
-    p.nbr = s->nbr.p; p.ncnt = s->ncnt.p; p.W = s->W; p.badj = s->badj.p; p.bdeg = s->bdeg.p; p.chain = s->chain.p;
+    p.nbr = s->nbr.p; p.nbr16 = s->nbr16.p; p.tiles = s->tiles.p; p.tiled = s->list_tiled ? 1 : 0; p.packed_ab = s->packed_ab ? 1 : 0;
+    p.cpb = s->cpb; p.tile_cap = s->tile_cap;
+    p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? 1 : 0;
+    p.ncnt = s->ncnt.p; p.W = s->W; p.badj = s->badj.p; p.bdeg = s->bdeg.p; p.chain = s->chain.p;
     p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.react_part = s->react_part.p; p.flags = s->flags.p;
     if (s->has_pair) {
         const gd_pair_softcore &q = s->pair;
@@ -559,11 +579,20 @@ static void fill_common(gd_system *s, StepParams &p)
 }
 
 // Enqueue one list build (counting sort into slot order + ELL fill) with radius rv.
-static int enqueue_build(gd_system *s, float rv, bool with_list)
+static bool want_tiled(const gd_system *s)
 {
-    if (with_list && (s->W == 0 || !s->nbr.p)) {
-        if (s->W == 0) s->W = 32;
-        HIPCHK(s->nbr.resize((size_t)s->W * s->R * s->Np, false));
+    return s->kernel_path != 1 && s->tiled_ok && s->box_kind == GD_BOX_OPEN && s->packed_ab;
+}
+
+static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tiled = true)
+{
+    const bool tiled = with_list && allow_tiled && want_tiled(s);
+    if (with_list) {
+        if (s->W == 0) s->W = 48;
+        s->W = (s->W + GD_UNROLL - 1) & ~(GD_UNROLL - 1);
+        const size_t need = (size_t)s->W * s->R * s->Np;   // entries; chunked wave-interleaved layout (k_step)
+        if (tiled) { if (s->nbr16.n != need) HIPCHK(s->nbr16.resize(need, false)); }
+        else if (s->nbr.n != need) HIPCHK(s->nbr.resize(need, false));
     }
     BuildParams b;
     memset(&b, 0, sizeof b);
@@ -578,9 +607,12 @@ static int enqueue_build(gd_system *s, float rv, bool with_list)
     b.ab_o = s->ab_o.p; b.mob_o = s->mob_o.p; b.bendE_o = s->bendE_o.p; b.psmask_o = s->psmask_o.p;
     b.badj_o = s->badj_o.p; b.bdeg_o = s->bdeg_o.p; b.chain_o = s->has_bend ? s->chain_o.p : nullptr; b.WB = s->WB;
     b.ab = s->ab.p; b.mob = s->mobs.p; b.bendE = s->bendE.p; b.psmask = s->psmask.p; b.badj = s->badj.p; b.bdeg = s->bdeg.p;
-    b.chain = s->chain.p; b.nbr = with_list ? s->nbr.p : nullptr; b.ncnt = s->ncnt.p; b.W = s->W;
+    b.chain = s->chain.p; b.nbr = (with_list && !tiled) ? s->nbr.p : nullptr; b.nbr16 = tiled ? s->nbr16.p : nullptr;
+    b.ncnt = s->ncnt.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
+    b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p;
     gd_launch_build(b, s->stream);
+    s->list_tiled = tiled;
     s->pcur ^= 1; s->ocur ^= 1;
     s->rv = rv; s->steps_since_build = 0; s->rebuilds++;
     s->timing.rebuild_launches++;
@@ -589,6 +621,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list)
 
 static int read_flags(gd_system *s, std::vector<unsigned> &f)
 {
+    HIPCHK(hipGetLastError());
     f.resize((size_t)s->R * GD_NFLAGS);
     HIPCHK(hipMemcpyAsync(f.data(), s->flags.p, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -596,23 +629,52 @@ static int read_flags(gd_system *s, std::vector<unsigned> &f)
 }
 static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (size_t)s->R * GD_NFLAGS * sizeof(unsigned), s->stream)); return GD_OK; }
 
-// Synchronous build used outside gd_run: grows the list width until nothing overflows.
-static int build_now(gd_system *s, float rv, bool with_list)
+// React to list-width / tile-capacity overflow flags: widen the list, enlarge the LDS tile or
+// fall back to the generic path. Returns true when a build has to be redone.
+static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
 {
-    for (int attempt = 0; attempt < 8; attempt++) {
+    unsigned need_w = 0, need_t = 0; bool over = false, tover = false;
+    for (uint32_t r = 0; r < s->R; r++) {
+        over |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] != 0; need_w = std::max(need_w, f[r * GD_NFLAGS + GD_FLAG_NEED_W]);
+        tover |= f[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] != 0; need_t = std::max(need_t, f[r * GD_NFLAGS + GD_FLAG_NEED_TILE]);
+    }
+    if (!tover && !over && s->list_tiled && need_t > 0) {
+        // size the LDS tile to what the builds actually need (more resident blocks per CU)
+        const unsigned want = std::min(9728u, need_t + need_t / 6 + 64);
+        if (want > s->tile_cap || want + want / 4 < s->tile_cap) s->tile_cap = want;
+    }
+    if (tover) {
+        const unsigned cap = need_t + need_t / 8 + 64;
+        if (cap <= 9728) s->tile_cap = cap;    // < 160 KB of LDS per CU incl. the static part
+        else s->tiled_ok = false;                // too dense for one tile: generic path
+    }
+    if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
+    if (tover && getenv("GDYN_DEBUG")) {
+        std::vector<GridP> gp(s->R);
+        (void)hipMemcpy(gp.data(), s->grid.p, s->R * sizeof(GridP), hipMemcpyDeviceToHost);
+        for (uint32_t r = 0; r < std::min(s->R, 3u); r++)
+            fprintf(stderr, "[gdyn] grid r%u: nc %d %d %d ncell %d org %g %g %g inv %g flags need_t %u\n", r, gp[r].nc[0], gp[r].nc[1], gp[r].nc[2],
+                    gp[r].ncell, gp[r].org[0], gp[r].org[1], gp[r].org[2], gp[r].inv[0], f[r * GD_NFLAGS + GD_FLAG_NEED_TILE]);
+    }
+    if ((over || tover) && getenv("GDYN_DEBUG"))
+        fprintf(stderr, "[gdyn] overflow: list %d (need %u -> W %u), tile %d (need %u -> cap %u, tiled_ok %d)\n", (int)over, need_w, s->W,
+                (int)tover, need_t, s->tile_cap, (int)s->tiled_ok);
+    return over || tover;
+}
+
+// Synchronous build used outside gd_run: grows the list width until nothing overflows.
+static int build_now(gd_system *s, float rv, bool with_list, bool allow_tiled = true)
+{
+    for (int attempt = 0; attempt < 10; attempt++) {
         GDCHK(clear_flags(s));
-        GDCHK(enqueue_build(s, rv, with_list));
+        GDCHK(enqueue_build(s, rv, with_list, allow_tiled));
         std::vector<unsigned> f;
         GDCHK(read_flags(s, f));
-        unsigned need = 0; bool over = false;
-        for (uint32_t r = 0; r < s->R; r++) { over |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] != 0; need = std::max(need, f[r * GD_NFLAGS + GD_FLAG_NEED_W]); }
-        if (!over) {
+        if (!handle_overflow(s, f)) {
             HIPCHK(hipMemcpy(s->lcount.data(), s->lcount_d.p, s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             GDCHK(clear_flags(s));
             return GD_OK;
         }
-        s->W = std::max(need + need / 4 + 4, s->W * 2);
-        HIPCHK(s->nbr.resize((size_t)s->W * s->R * s->Np, false));
     }
     return fail(GD_ENOMEM, "neighbour list width did not converge (W=%u)", s->W);
 }
@@ -728,13 +790,12 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         HIPCHK(hipEventRecord(ev_end, s->stream));
         std::vector<unsigned> f;
         GDCHK(read_flags(s, f));
-        bool violated = false, over = false; unsigned need = 0; float maxd2 = 0;
+        bool violated = false; float maxd2 = 0;
         for (uint32_t r = 0; r < s->R; r++) {
             violated |= f[r * GD_NFLAGS + GD_FLAG_VIOLATION] != 0;
-            over |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] != 0;
-            need = std::max(need, f[r * GD_NFLAGS + GD_FLAG_NEED_W]);
             float d2; memcpy(&d2, &f[r * GD_NFLAGS + GD_FLAG_MAXDISP2], 4); maxd2 = std::max(maxd2, d2);
         }
+        const bool over = handle_overflow(s, f);
         if (violated || over) {
             // roll the chunk back: restore bead-order positions + context, shorten the interval / widen the list
             s->rollbacks++;
@@ -744,8 +805,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             s->hctx = snap_ctx; s->ctx_dirty = true;
             GDCHK(upload_ctx(s));
             s->list_valid = false;
-            if (over) { s->W = std::max(need + need / 4 + 4, s->W * 2); HIPCHK(s->nbr.resize((size_t)s->W * s->R * s->Np, false)); }
-            if (violated) {
+            if (violated && !over) {
                 if (s->K == 1) {
                     if (s->skin > 8) return fail(GD_ESTATE, "gd_run: Verlet skin cannot cover one step (timestep too large?)");
                     s->skin *= 1.5;
@@ -830,18 +890,22 @@ extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *
     if (!s || !n_pairs || (cap && !pairs)) return fail(GD_EINVAL, "gd_search_pairs: NULL argument");
     if (r >= s->R || !(dcut > 0)) return fail(GD_EINVAL, "gd_search_pairs: bad replica or cutoff");
     GDCHK(prepare(s));
-    GDCHK(build_now(s, (float)dcut, true));
+    GDCHK(build_now(s, (float)dcut, true, false));   // generic (global-slot) list
     s->list_valid = false;   // the force list was overwritten with the search radius
-    const uint32_t N = s->N, W = s->W;
-    std::vector<unsigned> cnt(N), org(N), nb((size_t)W * N);
+    const uint32_t N = s->N, W = s->W, NC = W / 4;
+    std::vector<unsigned> cnt(N), org(N);
     HIPCHK(hipMemcpy(cnt.data(), s->ncnt.p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(org.data(), s->orig[s->ocur].p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy2D(nb.data(), (size_t)N * sizeof(unsigned), s->nbr.p + (size_t)r * s->Np, (size_t)s->R * s->Np * sizeof(unsigned),
-                       (size_t)N * sizeof(unsigned), W, hipMemcpyDeviceToHost));
+    // generic list layout: chunk c (4 slots) of bead g is uint4 #((g/64)*NC + c)*64 + g%64
+    const size_t wave0 = ((size_t)r * s->Np) / 64, nwaves = s->Np / 64;
+    std::vector<uint4> lst((size_t)nwaves * NC * 64);
+    HIPCHK(hipMemcpy(lst.data(), (const uint4 *)s->nbr.p + wave0 * NC * 64, lst.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     uint64_t n = 0;
     for (uint32_t sl = 0; sl < N; sl++)
         for (uint32_t k = 0; k < cnt[sl]; k++) {
-            const uint32_t i = org[sl], j = org[nb[(size_t)k * N + sl]];
+            const uint4 q = lst[((size_t)(sl / 64) * NC + k / 4) * 64 + sl % 64];
+            const unsigned js = (k % 4 == 0) ? q.x : (k % 4 == 1) ? q.y : (k % 4 == 2) ? q.z : q.w;
+            const uint32_t i = org[sl], j = org[js];
             if (i < j) { if (n < cap) { pairs[2 * n] = i; pairs[2 * n + 1] = j; } n++; }
         }
     *n_pairs = n;

@@ -13,6 +13,8 @@
 //                          binning, counting sort into slot order, ELL Verlet list fill.
 //
 // MFMA is not used: the path is an irregular short-range N-body sum.
+#include <hip/hip_fp16.h>
+
 #include "gdyn_types.h"
 
 #define TERM_PAIR 1u
@@ -32,6 +34,47 @@
 #define POT_SOFTCORE 3
 
 // ------------------------------------------------------------------ helpers
+
+// XCD-aware block mapping: the dispatcher deals workgroups round-robin over the 8 XCDs, so
+// physical block b runs on XCD b%8.  Every XCD gets one contiguous chunk (cpb blocks = a slab
+// of cell-sorted slots) of every replica, so the halo re-reads of neighbouring blocks hit that
+// XCD's L2.  Speed only: any placement gives the same results.
+__device__ __forceinline__ bool block_map(unsigned b, unsigned nblk, unsigned cpb, unsigned &r, unsigned &blk)
+{
+    const unsigned xcd = b % GD_XCDS, q = b / GD_XCDS;
+    r = q / cpb;
+    blk = xcd * cpb + q % cpb;
+    return blk < nblk;
+}
+
+__device__ __forceinline__ float2 unpack_ab(float w)
+{
+    const unsigned u = __float_as_uint(w);
+    return make_float2(__half2float(__ushort_as_half((unsigned short)(u & 0xffffu))),
+                       __half2float(__ushort_as_half((unsigned short)(u >> 16))));
+}
+__device__ __forceinline__ float pack_ab(float2 ab)
+{
+    const unsigned lo = __half_as_ushort(__float2half_rn(ab.x)), hi = __half_as_ushort(__float2half_rn(ab.y));
+    return __uint_as_float(lo | (hi << 16));
+}
+
+// softcore<2,3> + softcore<8,3> (the pair force of all four reference models), branch-free:
+// the clamp makes each term vanish beyond its own diameter.  ca = 6 eps_a / sa^2, cb = 24 eps_b / sb^2.
+__device__ __forceinline__ float softcore_2383(float r2, float inv_sa2, float inv_sb2, float ca, float cb, float wa, float wb)
+{
+    const float ga = fmaxf(1.0f - r2 * inv_sa2, 0.0f);
+    const float u2 = r2 * inv_sb2, u4 = u2 * u2;
+    const float gb = fmaxf(1.0f - u4 * u4, 0.0f);
+    return wa * ca * ga * ga + wb * cb * gb * gb * u4 * u2;
+}
+__device__ __forceinline__ float softcore_2383_energy(float r2, float inv_sa2, float inv_sb2, float ea, float eb, float wa, float wb)
+{
+    const float ga = fmaxf(1.0f - r2 * inv_sa2, 0.0f);
+    const float u2 = r2 * inv_sb2, u4 = u2 * u2;
+    const float gb = fmaxf(1.0f - u4 * u4, 0.0f);
+    return wa * ea * ga * ga * ga + wb * eb * gb * gb * gb;
+}
 
 __device__ __forceinline__ float wave_sum_f(float v)
 {
@@ -183,29 +226,40 @@ struct CtxF {
 
 // ------------------------------------------------------------------- k_step
 
-template <int MODE, bool PERIODIC>
+// TILED: the block first stages its LDS tile (its own 256 slots + all slots of the adjacent
+// cells, 9 contiguous slot ranges, TileDesc) with coalesced loads; pair-list entries are 16-bit
+// indices into that tile, so the neighbour gather is an LDS read.  PK=1: softcore<2,3>+<8,3>.
+template <int MODE, bool PERIODIC, bool TILED, int PK>
 __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ BondType s_bt[GD_MAX_BOND_TYPES];
     __shared__ CtxF s_ctx;
     __shared__ float s_red[GD_BLOCK / 64][4];
     __shared__ double s_e[GD_BLOCK / 64];
 
-    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    unsigned r, blk;
+    if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t rbase = (size_t)r * p.Np;
+    const float4 *__restrict__ rpos = p.pos_in + rbase;
 
     for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
+    if (TILED) {
+        const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
+#pragma unroll
+        for (int k = 0; k < GD_TILE_RANGES; k++) {
+            const unsigned len = td->len[k], st = td->start[k], base = td->base[k];
+            for (unsigned q = tid; q < len; q += GD_BLOCK) s_tile[base + q] = rpos[st + q];
+        }
+    }
     if (wid == 0) {
         DevCtx c = p.ctx_in[r];
         if (MODE == GD_MODE_STEP) {
             if (c.pending) apply_callback(c, p, r, lane);
-            if (lane == 0) {
-                s_ctx.bead_scale = (float)c.bead_scale; s_ctx.bond_scale = (float)c.bond_scale;
-                s_ctx.semi[0] = (float)c.semi[0]; s_ctx.semi[1] = (float)c.semi[1]; s_ctx.semi[2] = (float)c.semi[2];
-                s_ctx.step = c.step;
-                if (blk == 0) { c.pending = 1; p.ctx_out[r] = c; }
-            }
-        } else if (lane == 0) {
+            if (lane == 0 && blk == 0) { DevCtx o = c; o.pending = 1; p.ctx_out[r] = o; }
+        }
+        if (lane == 0) {
             s_ctx.bead_scale = (float)c.bead_scale; s_ctx.bond_scale = (float)c.bond_scale;
             s_ctx.semi[0] = (float)c.semi[0]; s_ctx.semi[1] = (float)c.semi[1]; s_ctx.semi[2] = (float)c.semi[2];
             s_ctx.step = c.step;
@@ -215,7 +269,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 
     const unsigned slot = blk * GD_BLOCK + tid;
     const bool valid = slot < p.N;
-    const size_t rbase = (size_t)r * p.Np;
     const size_t g = rbase + slot;
     const unsigned mask = (MODE == GD_MODE_STEP) ? 63u : p.term_mask;
 
@@ -227,7 +280,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     if (valid) {
         const float4 xi4 = p.pos_in[g];
         const float3 xi = make_float3(xi4.x, xi4.y, xi4.z);
-        const float4 *__restrict__ rpos = p.pos_in + rbase;
         const float2 *__restrict__ rab = p.ab + rbase;
         const float2 abi = p.ab[g];
 
@@ -237,23 +289,59 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             const float sa = p.pair.sigma_a * sc, sb = p.pair.sigma_b * sc;
             const float inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f, inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
             const float cut = p.pair.cutoff * sc, cut2 = cut * cut;
+            const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb = 24.0f * p.pair.eps_b * inv_sb2;
             const unsigned cnt = p.ncnt[g];
-            const unsigned *__restrict__ col = p.nbr + g;
-            for (unsigned k = 0; k < cnt; k++) {
-                const unsigned j = col[(size_t)k * p.stride];
-                const float4 xj = rpos[j];
-                float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
-                if (PERIODIC) d = min_image(d, p.box, p.inv_box);
-                const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                if (r2 < cut2) {
+            // Pair lists are stored in chunks of 16 bytes per bead, wave-interleaved:
+            // chunk c of bead g is uint4 #((g/64)*NC + c)*64 + g%64  (one coalesced 1 KiB read per wave).
+            // Tiled: 8 x u16 tile indices per chunk; generic: 4 x u32 slots per chunk.
+            const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(g >> 6) * (TILED ? p.W / 8 : p.W / 4) * 64 + (g & 63);
+            const bool mix = p.pair.mix != 0;
+            // The list is padded to a multiple of GD_UNROLL with the bead's own index (zero
+            // displacement => zero force), so every batch issues its index loads and its
+            // neighbour reads together and the loop body has no bounds test.
+            const unsigned cntp = (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
+            for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
+                unsigned jj[GD_UNROLL];
+                float4 xjv[GD_UNROLL];
+                if (TILED) {
+                    const uint4 q = lst[(size_t)(k0 / 8) * 64];
+                    jj[0] = q.x & 0xffffu; jj[1] = q.x >> 16; jj[2] = q.y & 0xffffu; jj[3] = q.y >> 16;
+                    jj[4] = q.z & 0xffffu; jj[5] = q.z >> 16; jj[6] = q.w & 0xffffu; jj[7] = q.w >> 16;
+                } else {
+                    const uint4 q0 = lst[(size_t)(k0 / 4) * 64], q1 = lst[(size_t)(k0 / 4 + 1) * 64];
+                    jj[0] = q0.x; jj[1] = q0.y; jj[2] = q0.z; jj[3] = q0.w; jj[4] = q1.x; jj[5] = q1.y; jj[6] = q1.z; jj[7] = q1.w;
+                }
+#pragma unroll
+                for (int u = 0; u < GD_UNROLL; u++) xjv[u] = TILED ? s_tile[jj[u]] : rpos[jj[u]];
+#pragma unroll
+                for (int u = 0; u < GD_UNROLL; u++) {
+                    const float4 xj = xjv[u];
+                    const unsigned j = jj[u];
+                    float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+                    if (PERIODIC) d = min_image(d, p.box, p.inv_box);
+                    const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
                     float wa = 1.0f, wb = 1.0f;
-                    if (p.pair.mix) { const float2 abj = rab[j]; wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y); }
-                    float ea, fa, eb, fb;
-                    softcore(p.pair.eps_a, inv_sa2, p.pair.p_a, p.pair.q_a, r2, ea, fa);
-                    softcore(p.pair.eps_b, inv_sb2, p.pair.p_b, p.pair.q_b, r2, eb, fb);
-                    const float f = wa * fa + wb * fb;
-                    F.x += f * d.x; F.y += f * d.y; F.z += f * d.z;
-                    if (MODE == GD_MODE_ENERGY) E += 0.5f * (wa * ea + wb * eb);
+                    if (PK == 1) {
+                        if (mix) {
+                            const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
+                            wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y);
+                        }
+                        const float f = softcore_2383(r2, inv_sa2, inv_sb2, ca, cb, wa, wb);
+                        F.x += f * d.x; F.y += f * d.y; F.z += f * d.z;
+                        if (MODE == GD_MODE_ENERGY && k0 + u < cnt)
+                            E += 0.5f * softcore_2383_energy(r2, inv_sa2, inv_sb2, p.pair.eps_a, p.pair.eps_b, wa, wb);
+                    } else if (r2 < cut2) {
+                        if (mix) {
+                            const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
+                            wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y);
+                        }
+                        float ea, fa, eb, fb;
+                        softcore(p.pair.eps_a, inv_sa2, p.pair.p_a, p.pair.q_a, r2, ea, fa);
+                        softcore(p.pair.eps_b, inv_sb2, p.pair.p_b, p.pair.q_b, r2, eb, fb);
+                        const float f = wa * fa + wb * fb;
+                        F.x += f * d.x; F.y += f * d.y; F.z += f * d.z;
+                        if (MODE == GD_MODE_ENERGY && k0 + u < cnt) E += 0.5f * (wa * ea + wb * eb);
+                    }
                 }
             }
             if (MODE == GD_MODE_STEP) {
@@ -274,15 +362,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             for (unsigned k = 0; k < deg; k++) {
                 const unsigned ent = col[(size_t)k * p.stride];
                 const unsigned j = ent & GD_ADJ_MASK;
-                const BondType bt = s_bt[ent >> GD_ADJ_SHIFT];
+                const BondType bt = s_bt[(ent >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1)];
                 if (!(mask & (unsigned)bt.term)) continue;
-                const float4 xj = rpos[j];
+                float4 xj;
+                if (TILED && (ent & GD_ADJ_LOCAL)) xj = s_tile[j]; else xj = rpos[j];
                 float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
                 if (PERIODIC && bt.minimg) d = min_image(d, p.box, p.inv_box);
                 const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
                 float K = bt.ka, l = bt.la;
                 if (bt.mix) {
-                    const float2 abj = rab[j];
+                    const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
                     const float a = 0.5f * (abi.x + abj.x), b = 0.5f * (abi.y + abj.y);
                     K = a * bt.ka + b * bt.kb; l = a * bt.la + b * bt.lb;
                 }
@@ -300,10 +389,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             if (be.x != 0.f || be.y != 0.f || be.z != 0.f) {
                 const int4 c4 = p.chain[g];
                 float3 xm2 = xi, xm1 = xi, xp1 = xi, xp2 = xi;
-                if (c4.x >= 0) { const float4 t = rpos[c4.x]; xm2 = make_float3(t.x, t.y, t.z); }
-                if (c4.y >= 0) { const float4 t = rpos[c4.y]; xm1 = make_float3(t.x, t.y, t.z); }
-                if (c4.z >= 0) { const float4 t = rpos[c4.z]; xp1 = make_float3(t.x, t.y, t.z); }
-                if (c4.w >= 0) { const float4 t = rpos[c4.w]; xp2 = make_float3(t.x, t.y, t.z); }
+                auto fetch = [&](int c) -> float3 {
+                    float4 t;
+                    if (TILED && (c & GD_CHAIN_LOCAL)) t = s_tile[c & 0xffff]; else t = rpos[c];
+                    return make_float3(t.x, t.y, t.z);
+                };
+                if (c4.x >= 0) xm2 = fetch(c4.x);
+                if (c4.y >= 0) xm1 = fetch(c4.y);
+                if (c4.z >= 0) xp1 = fetch(c4.z);
+                if (c4.w >= 0) xp2 = fetch(c4.w);
                 float3 fi, fk; float cs;
                 if (be.x != 0.f) {   // (i-2, i-1, i): this bead is the last one
                     const float3 d1 = make_float3(xm1.x - xm2.x, xm1.y - xm2.y, xm1.z - xm2.z);
@@ -443,18 +537,31 @@ __global__ __launch_bounds__(64) void k_finalize(const StepParams p, int reduce_
     if (lane == 0) p.ctx_out[r] = c;
 }
 
+template <int MODE>
+static void launch_step_mode(const StepParams &p, hipStream_t st)
+{
+    const dim3 grid(GD_XCDS * p.cpb * p.R), block(GD_BLOCK);
+    const size_t lds = p.tiled ? (size_t)p.tile_cap * sizeof(float4) : 0;
+    if (p.tiled) {   // opt in to more than 64 KB of LDS per block (gfx950: 160 KB per CU)
+        static bool once = false;
+        if (!once) {
+            once = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        }
+    }
+#define L(PER, TIL, PK) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK>), grid, block, lds, st, p)
+    if (p.periodic) { if (p.pk) L(true, false, 1); else L(true, false, 0); }
+    else if (p.tiled) { if (p.pk) L(false, true, 1); else L(false, true, 0); }
+    else { if (p.pk) L(false, false, 1); else L(false, false, 0); }
+#undef L
+}
+
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st)
 {
-    const dim3 grid(p.R * p.nblk), block(GD_BLOCK);
-#define LAUNCH(M)                                                                     \
-    do {                                                                              \
-        if (p.periodic) hipLaunchKernelGGL((k_step<M, true>), grid, block, 0, st, p); \
-        else hipLaunchKernelGGL((k_step<M, false>), grid, block, 0, st, p);           \
-    } while (0)
-    if (mode == GD_MODE_STEP) LAUNCH(GD_MODE_STEP);
-    else if (mode == GD_MODE_FORCE) LAUNCH(GD_MODE_FORCE);
-    else LAUNCH(GD_MODE_ENERGY);
-#undef LAUNCH
+    if (mode == GD_MODE_STEP) launch_step_mode<GD_MODE_STEP>(p, st);
+    else if (mode == GD_MODE_FORCE) launch_step_mode<GD_MODE_FORCE>(p, st);
+    else launch_step_mode<GD_MODE_ENERGY>(p, st);
 }
 
 void gd_launch_finalize(const StepParams &p, int reduce_only, hipStream_t st)
@@ -601,86 +708,198 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
     const unsigned slot = blk * GD_BLOCK + threadIdx.x;
     if (slot >= p.N) return;
     const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
-    const unsigned ns = p.cell_start[(size_t)r * (p.ncell_cap + 1) + p.cell_id[g]] + p.rank[g];
+    const unsigned c = p.cell_id[g];
+    const unsigned ns = p.cell_start[(size_t)r * (p.ncell_cap + 1) + c] + p.rank[g];
     const unsigned o = p.orig_in[g];
-    const float4 x = p.pos_in[g];
+    float4 x = p.pos_in[g];
+    const float2 ab = p.ab_o[o];
+    if (p.packed_ab) x.w = pack_ab(ab);
     const size_t gn = rbase + ns;
     p.pos_out[gn] = x;
     p.xb[gn] = x;
     p.orig_out[gn] = o;
+    p.cell_s[gn] = c;
     p.slot_of[(size_t)r * p.N + o] = ns;
-    p.ab[gn] = p.ab_o[o];
+    p.ab[gn] = ab;
     p.mob[gn] = p.mob_o[o];
     p.bendE[gn] = p.bendE_o[o];
     p.psmask[gn] = p.psmask_o[o];
     p.bdeg[gn] = p.bdeg_o[o];
 }
 
+// One thread per block of slots: the (up to 9) slot ranges of its LDS tile. A block covers the contiguous
+// cell range [c0,c1] (cells are numbered x-fastest); the cells adjacent to any of them lie, for each
+// (dz,dy), in the linear range [c0+off-1, c1+off+1] with off = (dz*ny + dy)*nx (a superset).
+__global__ void k_tiles(const BuildParams p)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.R * p.nblk) return;
+    const unsigned r = t / p.nblk, blk = t % p.nblk;
+    const size_t rbase = (size_t)r * p.Np;
+    const GridP gp = p.grid[r];
+    const unsigned *__restrict__ cs = p.cell_start + (size_t)r * (p.ncell_cap + 1);
+    const unsigned first = blk * GD_BLOCK, last = min(first + GD_BLOCK, p.N) - 1;
+    const int c0 = (int)p.cell_s[rbase + first], c1 = (int)p.cell_s[rbase + last];
+    TileDesc td;
+    // the 9 (dz,dy) cell ranges come out ordered by their first cell; merge the overlapping ones
+    int mlo[GD_TILE_RANGES], mhi[GD_TILE_RANGES], nm = 0;
+    for (int k = 0; k < GD_TILE_RANGES; k++) {
+        const int dz = k / 3 - 1, dy = k % 3 - 1;
+        const int off = (dz * gp.nc[1] + dy) * gp.nc[0];
+        const int lo = max(c0 + off - 1, 0), hi = min(c1 + off + 1, gp.ncell - 1);
+        if (lo > hi) continue;
+        if (nm > 0 && lo <= mhi[nm - 1] + 1) mhi[nm - 1] = max(mhi[nm - 1], hi);
+        else { mlo[nm] = lo; mhi[nm] = hi; nm++; }
+    }
+    unsigned total = 0;
+    for (int k = 0; k < GD_TILE_RANGES; k++) {
+        unsigned st = 0, len = 0;
+        if (k < nm) { st = cs[mlo[k]]; len = cs[mhi[k] + 1] - st; }
+        if (total + len > p.tile_cap) {   // does not fit the LDS budget: flag, host rolls back and re-plans
+            p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
+            atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total + len);
+            len = 0;
+        }
+        td.start[k] = st; td.len[k] = (unsigned short)len; td.base[k] = (unsigned short)total;
+        total += len;
+    }
+    td.total = total;
+    atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
+    p.tiles[t] = td;
+}
+
 // Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
-template <bool PERIODIC>
+// TILED: candidates are read from the block's LDS tile and list entries are tile indices.
+template <bool PERIODIC, bool TILED>
 __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
-    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    __shared__ TileDesc s_td;
+    unsigned r, blk;
+    if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
+    const float4 *__restrict__ rpos = p.pos_out + rbase;
+    if (TILED) {
+        if (threadIdx.x == 0) s_td = p.tiles[(size_t)r * p.nblk + blk];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GD_TILE_RANGES; k++) {
+            const unsigned len = s_td.len[k], st = s_td.start[k], base = s_td.base[k];
+            for (unsigned q = threadIdx.x; q < len; q += GD_BLOCK) s_tile[base + q] = rpos[st + q];
+        }
+        __syncthreads();
+    }
     unsigned cnt = 0;
     if (slot < p.N) {
         const unsigned o = p.orig_out[g];
         const unsigned *so = p.slot_of + (size_t)r * p.N;
+        auto to_local = [&](unsigned ps, unsigned &idx) -> bool {   // slot -> tile index
+#pragma unroll
+            for (int k = 0; k < GD_TILE_RANGES; k++) {
+                const unsigned d = ps - s_td.start[k];
+                if (d < s_td.len[k]) { idx = s_td.base[k] + d; return true; }
+            }
+            return false;
+        };
         const unsigned deg = p.bdeg_o[o];
         for (unsigned k = 0; k < deg; k++) {
             const unsigned ent = p.badj_o[(size_t)k * p.N + o];
-            p.badj[(size_t)k * p.stride + g] = so[ent & GD_ADJ_MASK] | (ent & ~GD_ADJ_MASK);
+            unsigned ps = so[ent & GD_ADJ_MASK], idx, out = ps | (ent & ~GD_ADJ_MASK);
+            if (TILED && to_local(ps, idx)) out = idx | (ent & ~GD_ADJ_MASK) | GD_ADJ_LOCAL;
+            p.badj[(size_t)k * p.stride + g] = out;
         }
         if (p.chain_o) {
-            int4 c = p.chain_o[o];
-            c.x = c.x >= 0 ? (int)so[c.x] : -1; c.y = c.y >= 0 ? (int)so[c.y] : -1;
-            c.z = c.z >= 0 ? (int)so[c.z] : -1; c.w = c.w >= 0 ? (int)so[c.w] : -1;
-            p.chain[g] = c;
+            const int4 c = p.chain_o[o];
+            auto conv = [&](int cb) -> int {
+                if (cb < 0) return -1;
+                const unsigned ps = so[cb];
+                unsigned idx;
+                if (TILED && to_local(ps, idx)) return (int)(idx | GD_CHAIN_LOCAL);
+                return (int)ps;
+            };
+            p.chain[g] = make_int4(conv(c.x), conv(c.y), conv(c.z), conv(c.w));
         }
-        if (p.nbr) {
+        if (p.nbr || p.nbr16) {
             const GridP gp = p.grid[r];
-            const float4 xi = p.pos_out[g];
-            const float4 *__restrict__ rpos = p.pos_out + rbase;
+            const float4 xi = rpos[slot];
             const unsigned *__restrict__ cs = p.cell_start + (size_t)r * (p.ncell_cap + 1);
             int cx, cy, cz;
             cell_coords<PERIODIC>(gp, xi, p.inv_box, cx, cy, cz);
             const float rv2 = p.rv * p.rv;
-            // distinct neighbour cells per dimension (small periodic grids alias)
-            const int nz = PERIODIC ? min(3, gp.nc[2]) : 3, ny = PERIODIC ? min(3, gp.nc[1]) : 3, nx = PERIODIC ? min(3, gp.nc[0]) : 3;
-            const int z0 = (PERIODIC && gp.nc[2] < 3) ? 0 : cz - 1, y0 = (PERIODIC && gp.nc[1] < 3) ? 0 : cy - 1,
-                      x0 = (PERIODIC && gp.nc[0] < 3) ? 0 : cx - 1;
-            unsigned *__restrict__ col = p.nbr + g;
-            for (int iz = 0; iz < nz; iz++) {
-                int zz = z0 + iz;
-                if (PERIODIC) zz = (zz + gp.nc[2]) % gp.nc[2]; else if (zz < 0 || zz >= gp.nc[2]) continue;
-                for (int iy = 0; iy < ny; iy++) {
-                    int yy = y0 + iy;
-                    if (PERIODIC) yy = (yy + gp.nc[1]) % gp.nc[1]; else if (yy < 0 || yy >= gp.nc[1]) continue;
-                    for (int ix = 0; ix < nx; ix++) {
-                        int xx = x0 + ix;
-                        if (PERIODIC) xx = (xx + gp.nc[0]) % gp.nc[0]; else if (xx < 0 || xx >= gp.nc[0]) continue;
-                        const unsigned c = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0] + xx);
-                        const unsigned b = cs[c], e = cs[c + 1];
-                        for (unsigned j = b; j < e; j++) {
-                            if (j == slot) continue;
-                            const float4 xj = rpos[j];
-                            float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
-                            if (PERIODIC) d = min_image(d, p.box, p.inv_box);
-                            if (d.x * d.x + d.y * d.y + d.z * d.z < rv2) {
-                                if (cnt < p.W) col[(size_t)cnt * p.stride] = j;
-                                cnt++;
+            // list writer: entries are collected in registers and stored 16 bytes at a time into the
+            // wave-interleaved chunk layout k_step reads (8 x u16 tiled, 4 x u32 generic)
+            constexpr unsigned PER = TILED ? 8u : 4u, BITS = TILED ? 16u : 32u;
+            const unsigned NC = p.W / PER;
+            uint4 *__restrict__ lst = (TILED ? (uint4 *)p.nbr16 : (uint4 *)p.nbr) + (size_t)(g >> 6) * NC * 64 + (g & 63);
+            unsigned long long lo = 0ull, hi = 0ull;
+            auto push = [&](unsigned j) {
+                const unsigned nb = cnt % PER;
+                if (nb < PER / 2) lo |= (unsigned long long)j << (BITS * nb);
+                else hi |= (unsigned long long)j << (BITS * (nb - PER / 2));
+                cnt++;
+                if (cnt % PER == 0) {
+                    const unsigned c = cnt / PER - 1;
+                    if (c < NC) lst[(size_t)c * 64] = make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+                    lo = 0ull; hi = 0ull;
+                }
+            };
+            if (TILED) {
+                const unsigned x_lo = (unsigned)max(cx - 1, 0), x_hi = (unsigned)min(cx + 1, gp.nc[0] - 1);
+#pragma unroll
+                for (int k = 0; k < GD_TILE_RANGES; k++) {
+                    const int zz = cz + k / 3 - 1, yy = cy + k % 3 - 1;
+                    if (zz < 0 || zz >= gp.nc[2] || yy < 0 || yy >= gp.nc[1]) continue;
+                    const unsigned row = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0]);
+                    const unsigned b = cs[row + x_lo], e = cs[row + x_hi + 1];
+                    unsigned lb = 0;
+                    if (e <= b || !to_local(b, lb)) continue;   // empty row (or a truncated, flagged tile)
+                    const unsigned le = lb + (e - b);
+                    for (unsigned j = lb; j < le; j++) {
+                        const float4 xj = s_tile[j];
+                        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                        if (dx * dx + dy * dy + dz * dz < rv2 && (b + (j - lb)) != slot) push(j);
+                    }
+                }
+            } else {
+                // distinct neighbour cells per dimension (small periodic grids alias)
+                const int nz = PERIODIC ? min(3, gp.nc[2]) : 3, ny = PERIODIC ? min(3, gp.nc[1]) : 3, nx = PERIODIC ? min(3, gp.nc[0]) : 3;
+                const int z0 = (PERIODIC && gp.nc[2] < 3) ? 0 : cz - 1, y0 = (PERIODIC && gp.nc[1] < 3) ? 0 : cy - 1,
+                          x0 = (PERIODIC && gp.nc[0] < 3) ? 0 : cx - 1;
+                for (int iz = 0; iz < nz; iz++) {
+                    int zz = z0 + iz;
+                    if (PERIODIC) zz = (zz + gp.nc[2]) % gp.nc[2]; else if (zz < 0 || zz >= gp.nc[2]) continue;
+                    for (int iy = 0; iy < ny; iy++) {
+                        int yy = y0 + iy;
+                        if (PERIODIC) yy = (yy + gp.nc[1]) % gp.nc[1]; else if (yy < 0 || yy >= gp.nc[1]) continue;
+                        for (int ix = 0; ix < nx; ix++) {
+                            int xx = x0 + ix;
+                            if (PERIODIC) xx = (xx + gp.nc[0]) % gp.nc[0]; else if (xx < 0 || xx >= gp.nc[0]) continue;
+                            const unsigned c = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0] + xx);
+                            const unsigned b = cs[c], e = cs[c + 1];
+                            for (unsigned j = b; j < e; j++) {
+                                if (j == slot) continue;
+                                const float4 xj = rpos[j];
+                                float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+                                if (PERIODIC) d = min_image(d, p.box, p.inv_box);
+                                if (d.x * d.x + d.y * d.y + d.z * d.z < rv2) push(j);
                             }
                         }
                     }
                 }
             }
-            if (cnt > p.W) {
+            const unsigned found = cnt;
+            if (found > p.W) {
                 p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
-                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], cnt);
+                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], found);
             }
-            p.ncnt[g] = min(cnt, p.W);
+            p.ncnt[g] = min(found, p.W);
+            // pad to a multiple of GD_UNROLL (W is one) with the bead itself: zero displacement, zero force
+            unsigned self = slot;
+            if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = idx; }
+            while (cnt % GD_UNROLL) push(self);
+            cnt = found;
         }
     }
     unsigned long long c64 = min(cnt, p.W);
@@ -696,7 +915,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 
 void gd_launch_build(const BuildParams &p, hipStream_t st)
 {
-    const dim3 grid(p.R * p.nblk), block(GD_BLOCK);
+    const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(GD_XCDS * p.cpb * p.R);
     hipLaunchKernelGGL(k_build_init, dim3((p.R + 63) / 64), dim3(64), 0, st, p);
     if (!p.periodic) hipLaunchKernelGGL(k_bbox, grid, block, 0, st, p);
     hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(64), 0, st, p);
@@ -705,8 +924,16 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
     else hipLaunchKernelGGL(k_bin<false>, grid, block, 0, st, p);
     hipLaunchKernelGGL(k_scan, dim3(p.R), dim3(1024), 0, st, p);
     hipLaunchKernelGGL(k_scatter, grid, block, 0, st, p);
-    if (p.periodic) hipLaunchKernelGGL(k_fill<true>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(k_fill<false>, grid, block, 0, st, p);
+    if (p.tiled) {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        }
+        hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
+        hipLaunchKernelGGL((k_fill<false, true>), gridx, block, (size_t)p.tile_cap * sizeof(float4), st, p);
+    } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false>), gridx, block, 0, st, p);
+    else hipLaunchKernelGGL((k_fill<false, false>), gridx, block, 0, st, p);
 }
 
 // ------------------------------------------------------------------- misc

@@ -12,15 +12,30 @@
 #include <stdint.h>
 
 #define GD_BLOCK 256
-#define GD_MAX_BOND_TYPES 64
+#define GD_MAX_BOND_TYPES 32
 #define GD_MAX_POINT_SOURCES 4
-#define GD_ADJ_SHIFT 26                    // bond adjacency entry = partner | type << 26
+#define GD_ADJ_SHIFT 26                    // bond adjacency entry = partner | type << 26 (| GD_ADJ_LOCAL)
 #define GD_ADJ_MASK ((1u << GD_ADJ_SHIFT) - 1u)
+#define GD_ADJ_LOCAL 0x80000000u           // tiled path: partner field is an index into the block's LDS tile
+#define GD_CHAIN_LOCAL 0x40000000          // same for chain (bending) partners
+#define GD_TILE_RANGES 9                   // (dz,dy) rows of the 27-cell neighbourhood
+#define GD_XCDS 8
+#define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 
 enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
 
 // flags[r*GD_NFLAGS + k]
-enum { GD_FLAG_VIOLATION = 0, GD_FLAG_OVERFLOW = 1, GD_FLAG_MAXDISP2 = 2, GD_FLAG_NEED_W = 3, GD_NFLAGS = 4 };
+enum { GD_FLAG_VIOLATION = 0, GD_FLAG_OVERFLOW = 1, GD_FLAG_MAXDISP2 = 2, GD_FLAG_NEED_W = 3, GD_FLAG_TILE_OVERFLOW = 4,
+       GD_FLAG_NEED_TILE = 5, GD_NFLAGS = 8 };
+
+// LDS tile of one block (tiled path): the block's 256 slots plus the slots of every cell adjacent
+// to its cells, as 9 contiguous slot ranges (one per (dz,dy) row offset of the cell grid).
+struct TileDesc {
+    unsigned start[GD_TILE_RANGES];        // first slot of the range
+    unsigned short len[GD_TILE_RANGES];    // slots in the range
+    unsigned short base[GD_TILE_RANGES];   // LDS index of the range's first slot
+    unsigned total;                        // beads staged
+};
 
 struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
     long long step;
@@ -86,8 +101,15 @@ struct StepParams {
     const unsigned char *psmask;
     // lists
     const unsigned *nbr;
+    const unsigned short *nbr16;        // tiled path: tile-local indices
+    const TileDesc *tiles;              // [R][nblk]
     const unsigned *ncnt;
     unsigned W;
+    int tiled;                          // 1: LDS-tiled path
+    int pk;                             // 1: softcore<2,3> + softcore<8,3> specialisation
+    int packed_ab;                      // 1: pos.w holds (a,b) as two fp16 (exactly representable)
+    unsigned cpb;                       // blocks per replica per XCD (XCD-aware block mapping)
+    unsigned tile_cap;                  // beads of LDS per block
     const unsigned *badj;
     const unsigned char *bdeg;
     const int4 *chain;                  // slots of (i-2, i-1, i+1, i+2) or -1
@@ -154,7 +176,12 @@ struct BuildParams {
     unsigned char *bdeg;
     int4 *chain;
     unsigned *nbr, *ncnt;
+    unsigned short *nbr16;
+    TileDesc *tiles;
+    unsigned *cell_s;                   // cell of each new slot
     unsigned W;
+    int tiled, packed_ab;
+    unsigned cpb, tile_cap;
     unsigned *flags;
     unsigned long long *lcount;         // [R] directed list entries
 };

@@ -66,8 +66,15 @@ def confined_random_walks(lens, radius, step, rng):
         s = rng.normal(size=(nch, 3))
         s *= step / np.linalg.norm(s, axis=1, keepdims=True)
         nxt = cur + s
+        for _ in range(8):   # steps that would leave the sphere are redrawn (no back-tracking onto old beads)
+            out = np.linalg.norm(nxt, axis=1) > 0.97 * radius
+            if not out.any():
+                break
+            s2 = rng.normal(size=(int(out.sum()), 3))
+            s2 *= step / np.linalg.norm(s2, axis=1, keepdims=True)
+            nxt[out] = cur[out] + s2
         out = np.linalg.norm(nxt, axis=1) > 0.97 * radius
-        nxt[out] = cur[out] - s[out]  # reflect the step
+        nxt[out] = cur[out] * (1 - step / radius)   # last resort: step towards the centre
         cur = nxt
     return pos
 

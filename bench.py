@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- bead-steps/s of the Brownian-dynamics hot path on the 100 kb whole-genome model.
+
+A "step" is one Brownian-dynamics step of every replica resident on a GPU (S-genome-30k,
+SURVEY.md section 8d: 46 chains, 30 000 beads, AB soft-core pairs + semispring chain bonds +
+(i,i+2) harmonic bonds + ellipsoid wall with on-device wall dynamics, T=1, dt=1e-5), R replicas
+batched per GPU, inputs resident in HBM.  N>1: one process per GPU (torch.distributed / RCCL),
+independent replicas per rank (weak scaling), RCCL only for the broadcast of the model inputs and
+the gather of summary statistics -- no data-path collective.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "2022a-genome-dynamics_amd"
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
+    """The oracle (CPU restatement, reference flags -O2 -msse4 -mno-avx, single thread, fp64,
+    mt19937_64 normals like the reference's RNG class) timed on this host: 1 replica of the same
+    workload, starting from the GPU-equilibrated positions."""
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    orc = g.Lib(path)
+    s, _ = wl.genome_interphase(orc, n_beads=n_beads, n_replicas=1)
+    s.set_positions(x0[None])
+    s.begin_phase()
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    t0 = time.perf_counter()
+    s.run(10, 1e-5, 1.0, seed=1, noise=g.NOISE_MT19937, flags=flags)
+    per = (time.perf_counter() - t0) / 10
+    steps = int(max(10, min(5000, budget_s / per)))
+    t0 = time.perf_counter()
+    s.run(steps, 1e-5, 1.0, seed=2, noise=g.NOISE_MT19937, flags=flags)
+    el = time.perf_counter() - t0
+    s.close()
+    return {"value": n_beads * steps / el, "unit": "bead-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} steps of 1 replica x {n_beads} beads (oracle/liboracle.so, fp64, Verlet list, "
+                      f"mt19937_64 normals, flags -O2 -march=x86-64 -msse4 -mno-avx), {el:.1f} s on 1 of {os.cpu_count()} host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--beads", type=int, default=30000)
+    ap.add_argument("--replicas", type=int, default=64, help="replicas batched per GPU")
+    ap.add_argument("--equil", type=int, default=2000, help="untimed relaxation steps before warmup")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skin", type=float, default=0.0)
+    ap.add_argument("--interval", type=int, default=0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    g = importlib.import_module(PKG)
+    wl = importlib.import_module(PKG + ".workloads")
+    hip = g.load()   # fails loudly if the HIP extension is missing
+
+    R, N = a.replicas, a.beads
+    # rank 0 generates the model inputs; RCCL broadcast to the farm (configs[4])
+    if rank == 0:
+        sys_, info = wl.genome_interphase(hip, n_beads=N, n_replicas=R, device=local_rank)
+        x0 = sys_.positions()
+    if world > 1:
+        shape = torch.tensor([R, N, 3], device="cuda")
+        dist.broadcast(shape, 0)
+        xt = torch.from_numpy(x0).cuda() if rank == 0 else torch.empty((R, N, 3), dtype=torch.float64, device="cuda")
+        dist.broadcast(xt, 0)
+        if rank != 0:
+            sys_, info = wl.genome_interphase(hip, n_beads=N, n_replicas=R, device=local_rank)
+            sys_.set_positions(xt.cpu().numpy())
+    if a.skin > 0 or a.interval > 0:
+        sys_.set_tuning(skin=a.skin, rebuild_interval=a.interval, adapt_interval=0 if a.interval else 1)
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    seed = wl.MASTER_SEED + 1000003 * rank    # independent trajectories per rank (and per replica index)
+    dt, kT = info["timestep"], info["temperature"]
+
+    sys_.begin_phase()
+    if a.equil > 0:
+        sys_.run(a.equil, dt, kT, seed=seed + 17, flags=0)      # relaxation: static scales / wall
+        sys_.begin_phase()
+    if a.warmup > 0:
+        sys_.run(a.warmup, dt, kT, seed=seed, flags=flags)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tm = sys_.run(a.steps, dt, kT, seed=seed, flags=flags)      # synchronous: returns after the stream drained
+    torch.cuda.synchronize(); barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    ctx = sys_.context(0)
+    e_mean = float(sys_.energy().mean() / N)
+    stats = torch.tensor([e_mean, ctx.semiaxes[0], float(ctx.rebuild_interval), float(ctx.rollbacks)], device="cuda", dtype=torch.float64)
+    if world > 1:   # gather of summary statistics (a few doubles per rank)
+        gathered = [torch.empty_like(stats) for _ in range(world)] if rank == 0 else None
+        dist.gather(stats, gathered, 0)
+    else:
+        gathered = [stats]
+
+    if rank == 0:
+        launches = max(int(tm.step_launches), 1)
+        L_launch = tm.list_entries_visited / launches                 # directed entries, all replicas
+        bytes_launch = 44.0 * N * R + 28.0 * L_launch                 # 44 N + 28 L per replica-step
+        kms = tm.step_kernel_ms / launches
+        achieved = bytes_launch / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "bead-steps/sec on 100kb whole-genome model, 1 GPU and 8-GPU replica farm",
+            "value": N * R * world * a.steps / el, "unit": "bead-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S-genome-{round(N / 1000)}k (5-sim-genome interphase force field, wall dynamics + scale updates on)",
+                       "n_beads": N, "replicas_per_gpu": R, "global_replicas": R * world, "parallelism": f"replica-farm x{world}",
+                       "timestep": dt, "temperature": kT, "list_entries_per_bead": L_launch / (N * R),
+                       "rebuild_interval": int(ctx.rebuild_interval), "list_radius": ctx.list_radius,
+                       "rollbacks": int(ctx.rollbacks), "equil_steps": a.equil,
+                       "mean_energy_per_bead": [float(s[0]) for s in gathered], "wall_semiaxis": [float(s[1]) for s in gathered]},
+            "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kms,
+                         "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(g, wl, sys_.positions()[0], N)
+            out["config"]["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    sys_.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

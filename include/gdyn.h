@@ -250,6 +250,7 @@ typedef struct {
     uint32_t adapt_interval;    /* 1 = adapt interval from measured displacements */
     uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
     uint32_t use_graph;         /* replay steps from a hipGraph */
+    uint32_t kernel_path;       /* 0 auto, 1 generic (global-gather lists), 2 LDS-tiled (open box, fp16-exact a/b) */
 } gd_tuning;
 
 int gd_set_tuning(gd_system *sys, const gd_tuning *t);

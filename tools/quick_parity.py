@@ -12,9 +12,10 @@ def cmp(name, a, b):
     d = np.abs(a - b).max(); s = np.abs(b).max()
     print(f"  {name}: max|diff| {d:.3e}  max|ref| {s:.3e}  rel {d/(s+1e-300):.2e}")
 
-def probe(builder, steps, dt, kT, flags=0, **kw):
-    print(builder.__name__, kw)
+def probe(builder, steps, dt, kT, flags=0, path=0, **kw):
+    print(builder.__name__, kw, "path", path)
     sh, info = builder(hip, **kw); so, _ = builder(orc, **kw)
+    sh.set_tuning(kernel_path=path)
     for t, nm in ((1, "pair"), (2, "bond"), (4, "bend"), (8, "point"), (16, "wall"), (32, "dyn"), (63, "all")):
         fo = so.forces(t)
         if np.abs(fo).max() == 0: continue
@@ -34,7 +35,9 @@ def probe(builder, steps, dt, kT, flags=0, **kw):
     return sh, so
 
 probe(wl.genome_interphase, 20, 1e-5, 1.0, flags=3, n_beads=2000, bead_scale_init=0.8)
+probe(wl.genome_interphase, 20, 1e-5, 1.0, flags=3, path=1, n_beads=2000, bead_scale_init=0.8)
 probe(wl.spindle, 20, 1e-4, 0.1, n_beads=300)
+probe(wl.spindle, 20, 1e-4, 0.1, path=1, n_beads=300)
 probe(wl.ab_box, 20, 1e-5, 1.0)
 probe(wl.chromatin_1kb, 20, 1e-4, 1.0, n_beads=4000, n_loops=40, n_glues=80)
 probe(wl.genome_interphase, 5, 1e-5, 1.0, flags=3, n_beads=3000, n_replicas=3)
