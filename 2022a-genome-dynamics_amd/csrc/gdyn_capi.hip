@@ -149,7 +149,7 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     s->cpb = (s->nblk + GD_XCDS - 1) / GD_XCDS;
     s->a.assign(s->N, 0.0); s->b.assign(s->N, 0.0); s->mob.assign(s->N, 1.0); s->bend.assign(s->N, 0.0);
     s->hctx.assign(s->R, DevCtx{});
-    for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; c.semi[0] = c.semi[1] = c.semi[2] = 1; }
+    for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; }   // wall_semiaxes {0,0,0} until a wall is set (simulation_context.hpp:16)
     s->lcount.assign(s->R, 0ull);
     s->ncell_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8ull * s->N, 4096ull), 262144ull);
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);

@@ -142,7 +142,7 @@ __device__ __forceinline__ void bond_pot(int kind, float K, float l, int P, int 
     } else {
         const float d = sqrtf(r2);
         const float x = d - l;
-        if (d > 0.0f && (kind == POT_SPRING || x > 0.0f)) { e = 0.5f * K * x * x; fr = -K * x / d; }
+        if (kind == POT_SPRING || x > 0.0f) { e = 0.5f * K * x * x; fr = d > 0.0f ? -K * x / d : 0.0f; }
     }
 }
 

@@ -1,0 +1,66 @@
+"""Replica farm over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in
+CPU tests).  The Brownian-dynamics path does not shard: one trajectory is a tightly coupled N-body
+system that fits one GPU many times over, while the ensemble is embarrassingly parallel (the
+reference runs one process per seed, 5-sim-genome/scripts/run_simulation:8-25, and averages
+replicas offline, 5-sim-genome/src/contact_map/contact_map.py:14-39).  So ranks own independent
+replicas; the only collectives are the broadcast of the model inputs before stepping and the gather
+of a few summary statistics afterwards -- nothing inside the timed loop."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world():
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def broadcast_array(arr, shape, dtype, device="cpu", src=0):
+    """Broadcast a numpy array from rank `src`; other ranks pass arr=None."""
+    import torch
+    rank, n = world()
+    if n == 1:
+        return arr
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(device) if rank == src else \
+        torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), device=device)
+    _dist().broadcast(t, src)
+    return t.cpu().numpy()
+
+
+def gather_stats(values, device="cpu", dst=0):
+    """Gather a short float vector from every rank to rank `dst` -> (world, k) array (None elsewhere)."""
+    import torch
+    rank, n = world()
+    v = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if n == 1:
+        return v.cpu().numpy()[None]
+    out = [torch.empty_like(v) for _ in range(n)] if rank == dst else None
+    _dist().gather(v, out, dst)
+    return torch.stack(out).cpu().numpy() if rank == dst else None
+
+
+def max_over_ranks(x, device="cpu"):
+    import torch
+    rank, n = world()
+    if n == 1:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    _dist().all_reduce(t, op=_dist().ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if world()[1] > 1:
+        _dist().barrier()
+
+
+def replica_seed(master_seed, rank):
+    """Independent noise streams per rank (the Philox counter carries the local replica index)."""
+    return int(master_seed) + 1000003 * int(rank)

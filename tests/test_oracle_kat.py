@@ -1,0 +1,241 @@
+"""Known-answer and consistency tests that pin the CPU oracle (no GPU needed).
+
+The reference has no tests or golden vectors for this path, so the
+oracle is pinned by published KAT vectors (Philox: Random123; mt19937_64: ISO C++ [rand.predef]),
+analytic two-body values, finite differences and brute-force cross-checks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import CASES, TERMS, build, g
+
+
+def test_philox_random123_kat(oracle):
+    f = oracle.dll.oracle_philox4x32_10
+    vecs = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, exp in vecs:
+        c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+        f(c, k, o)
+        assert tuple(o) == exp
+
+
+def test_mt19937_64_kat(oracle):
+    f = oracle.dll.oracle_mt64_nth
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_uint64, C.c_int]
+    assert f(5489, 10000) == 9981545732273789042      # [rand.predef] 10000th value of default mt19937_64
+
+
+def test_philox_normals_statistics(oracle):
+    f = oracle.dll.oracle_philox_normal3
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_uint32, C.POINTER(C.c_double)]
+    z = np.empty((20000, 3))
+    buf = (C.c_double * 3)()
+    for i in range(len(z)):
+        f(12345, i, 7, 0, buf)
+        z[i] = buf[:]
+    assert abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.03
+    assert abs(np.mean(z ** 4) - 3) < 0.15                      # Gaussian kurtosis
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.02
+
+
+def _two_bead(lib, r, setup, box=None):
+    s = g.System(lib, 2, 1, box=box)
+    setup(s)
+    s.set_positions(np.array([[0.0, 0, 0], [r, 0, 0]]))
+    return s
+
+
+@pytest.mark.parametrize("P,Q", [(2, 3), (8, 3), (4, 2), (12, 1), (6, 4)])
+def test_softcore_two_bead_analytic(oracle, P, Q):
+    eps, sig = 2.5, 0.3
+    for u in (0.25, 0.5, 0.999, 1.0, 1.5):
+        r = u * sig
+        s = _two_bead(oracle, r, lambda s: s.set_pair_softcore(eps, sig, 0.0, 0.0, P, Q, 8, 3, mix=False))
+        e_ref = eps * (1 - u ** P) ** Q if u < 1 else 0.0
+        f_ref = eps * P * Q / sig * (1 - u ** P) ** (Q - 1) * u ** (P - 1) if u < 1 else 0.0   # -dU/dr
+        assert s.energy()[0] == pytest.approx(e_ref, rel=1e-12, abs=1e-15)
+        F = s.forces()[0]
+        assert F[1, 0] == pytest.approx(f_ref, rel=1e-12, abs=1e-14)     # bead 1 pushed towards +x
+        assert F[0, 0] == pytest.approx(-f_ref, rel=1e-12, abs=1e-14)
+
+
+def test_ab_mixture_weights(oracle):
+    # a = (a_i+a_j)/2, b = (b_i+b_j)/2 (simulation_driver_forcefield.cc:32-33,44)
+    def setup(s):
+        s.set_bead_params(a=np.array([1.0, 0.5]), b=np.array([0.0, 5.0]))
+        s.set_pair_softcore(2.0, 0.30, 3.0, 0.24, 2, 3, 8, 3, mix=True)
+    r = 0.2
+    s = _two_bead(oracle, r, setup)
+    ua, ub = r / 0.30, r / 0.24
+    e = 0.75 * 2.0 * (1 - ua ** 2) ** 3 + 2.5 * 3.0 * (1 - ub ** 8) ** 3
+    assert s.energy()[0] == pytest.approx(e, rel=1e-12)
+
+
+@pytest.mark.parametrize("kind,K,b,r,e,f", [
+    (g.POT_HARMONIC, 70.0, 0.0, 0.3, 0.5 * 70 * 0.09, -70 * 0.3),
+    (g.POT_SPRING, 100.0, 1.0, 0.8, 0.5 * 100 * 0.04, +100 * 0.2),
+    (g.POT_SPRING, 100.0, 1.0, 1.3, 0.5 * 100 * 0.09, -100 * 0.3),
+    (g.POT_SEMISPRING, 500.0, 0.2, 0.15, 0.0, 0.0),          # one-sided: free below the rest length
+    (g.POT_SEMISPRING, 500.0, 0.2, 0.25, 0.5 * 500 * 0.0025, -500 * 0.05),
+])
+def test_bond_potentials_analytic(oracle, kind, K, b, r, e, f):
+    s = _two_bead(oracle, r, lambda s: s.add_bond_range(g.System.bond_params(kind, k_a=K, l_a=b), 0, 2, 1))
+    assert s.energy()[0] == pytest.approx(e, rel=1e-12, abs=1e-15)
+    assert s.forces()[0][1, 0] == pytest.approx(f, rel=1e-12, abs=1e-13)   # radial force on bead 1
+
+
+def test_bond_scale_and_mixing(oracle):
+    # K = (a Ka + b Kb)/s^2, l = (a la + b lb) s   (simulation_driver_forcefield.cc:60-77)
+    s = g.System(oracle, 2, 1)
+    s.set_bead_params(a=np.array([1.0, 0.0]), b=np.array([0.0, 1.0]))
+    s.add_bond_range(g.System.bond_params(g.POT_SEMISPRING, k_a=70, l_a=0.2, k_b=30, l_b=0.1, mix=True, scale_by_bond_scale=True), 0, 2, 1)
+    s.set_scaling(1.0, 1.0, 0.5, 1.0)
+    s.set_positions(np.array([[0.0, 0, 0], [0.2, 0, 0]]))
+    K, l = (0.5 * 70 + 0.5 * 30) / 0.25, (0.5 * 0.2 + 0.5 * 0.1) * 0.5
+    assert s.energy()[0] == pytest.approx(0.5 * K * (0.2 - l) ** 2, rel=1e-12)
+
+
+def test_bending_analytic(oracle):
+    # U = e (1 - cos theta): straight 0, right angle e, folded back 2e
+    for third, e_ref in (([2.0, 0, 0], 0.0), ([1.0, 1.0, 0], 1.5), ([0.0, 0, 0], 3.0)):
+        s = g.System(oracle, 3, 1)
+        s.add_bending_range(0, 3, 1.5)
+        s.set_positions(np.array([[0.0, 0, 0], [1.0, 0, 0], third]))
+        assert s.energy()[0] == pytest.approx(e_ref, abs=1e-12)
+    s = g.System(oracle, 3, 1)                                   # per-bead energy of the MIDDLE bead
+    s.set_bead_params(bending_energy=np.array([9.0, 2.0, 9.0]))
+    s.add_bending_range(0, 3, 0.0, per_bead=True)
+    s.set_positions(np.array([[0.0, 0, 0], [1.0, 0, 0], [1.0, 1.0, 0]]))
+    assert s.energy()[0] == pytest.approx(2.0, abs=1e-12)
+
+
+def test_sphere_wall_exact(oracle):
+    # a=b=c: the second-order surface construction is exact; inward soft wall with half diameters,
+    # outward harmonic, axial reaction sums to the normal force.
+    R, eps, sig = 2.0, 2.0, 0.3
+    for dist_in in (0.05, 0.1, 0.2):
+        s = g.System(oracle, 1, 1)
+        s.set_bead_params(a=np.array([1.0]), b=np.array([0.0]))
+        s.set_ellipsoid_wall(eps, sig, 0.0, 0.24, 1.0, 0.0, 5000.0, (1e4,) * 3, 1e-4, (R,) * 3, scale_by_bead_scale=False)
+        n = np.array([1.0, 2.0, 2.0]) / 3.0
+        s.set_positions((n * (R - dist_in))[None])
+        u = dist_in / (sig / 2)
+        e_ref = eps * (1 - u * u) ** 3 if u < 1 else 0.0      # wall a-weight = (1+1)/2
+        f_ref = eps * 6 / (sig / 2) * (1 - u * u) ** 2 * u if u < 1 else 0.0
+        assert s.energy()[0] == pytest.approx(e_ref, rel=1e-9, abs=1e-13)
+        F = s.forces()[0, 0]
+        assert np.allclose(F, -f_ref * n, rtol=1e-9, atol=1e-12)    # pushed inwards
+        react = np.array(s.context().axial_reaction)
+        assert react.sum() == pytest.approx(f_ref, rel=1e-9, abs=1e-12)
+    s = g.System(oracle, 1, 1)
+    s.set_ellipsoid_wall(eps, sig, 0.0, 0.24, 1.0, 0.0, 5000.0, (1e4,) * 3, 1e-4, (R,) * 3)
+    s.set_positions(np.array([[0.0, 0.0, R + 0.1]]))
+    assert s.energy()[0] == pytest.approx(0.5 * 5000 * 0.01, rel=1e-9)
+    assert s.forces()[0, 0, 2] == pytest.approx(-5000 * 0.1, rel=1e-9)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_force_is_minus_gradient(oracle, name):
+    s, *_ = build(oracle, name)
+    x0 = s.positions()
+    rng = np.random.default_rng(3)
+    F = s.forces()
+    h = 1e-6
+    for i in rng.choice(s.N, 12, replace=False):
+        for k in range(3):
+            xp = x0.copy(); xp[0, i, k] += h; s.set_positions(xp); ep = s.energy()[0]
+            xm = x0.copy(); xm[0, i, k] -= h; s.set_positions(xm); em = s.energy()[0]
+            assert F[0, i, k] == pytest.approx(-(ep - em) / (2 * h), rel=2e-5, abs=2e-4)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_internal_forces_sum_to_zero(oracle, name):
+    s, *_ = build(oracle, name)
+    internal = g.TERM_PAIR | g.TERM_BOND | g.TERM_BEND | g.TERM_DYNAMIC
+    F = s.forces(internal)
+    assert np.abs(F.sum(axis=1)).max() <= 1e-9 * np.abs(F).sum()
+
+
+@pytest.mark.parametrize("box", [None, (2.9,) * 3, (0.9, 1.3, 2.9)])
+def test_neighbor_search_equals_bruteforce(oracle, box):
+    rng = np.random.default_rng(5)
+    n = 1500
+    x = rng.random((n, 3)) * (np.array(box) if box else 3.0) * (1.3 if box else 1.0)   # periodic: also outside the cell
+    x[:50] = np.round(x[:50] / 0.3) * 0.3          # beads exactly on cell boundaries
+    s = g.System(oracle, n, 1, box=box)
+    s.set_positions(x)
+    oracle.dll.oracle_set_bruteforce(s._h, 0)
+    cells = {tuple(p) for p in s.search_pairs(0.3)}
+    oracle.dll.oracle_set_bruteforce(s._h, 1)
+    brute = {tuple(p) for p in s.search_pairs(0.3)}
+    assert cells == brute and len(brute) > 100
+
+
+def test_verlet_list_trajectory_equals_bruteforce(oracle):
+    out = []
+    for brute in (1, 0):
+        s, dt, kT, flags = build(oracle, "genome")
+        oracle.dll.oracle_set_bruteforce(s._h, brute)
+        s.begin_phase()
+        s.run(60, dt, kT, seed=11, flags=flags)
+        out.append(s.positions())
+    assert np.abs(out[0] - out[1]).max() < 1e-11
+
+
+def test_free_diffusion_msd(oracle):
+    # <|dx|^2> = 6 mu kT t for free beads (Euler-Maruyama noise scale sqrt(2 mu kT dt))
+    n, steps, dt, kT = 4000, 50, 1e-3, 0.7
+    s = g.System(oracle, n, 1)
+    mu = np.full(n, 1.0); mu[n // 2:] = 2.0
+    s.set_bead_params(mobility=mu)
+    s.set_positions(np.zeros((n, 3)))
+    s.run(steps, dt, kT, seed=5)
+    d2 = (s.positions()[0] ** 2).sum(axis=1)
+    for sel, m in ((slice(0, n // 2), 1.0), (slice(n // 2, n), 2.0)):
+        assert d2[sel].mean() == pytest.approx(6 * m * kT * steps * dt, rel=0.06)
+
+
+def test_callback_state_sequence(oracle):
+    # bead/bond scale follow 1-(1-s0)exp(-t/tau) with t = step*dt; the wall follows its ODE
+    s, dt, kT, flags = build(oracle, "genome")
+    s.begin_phase()
+    R0 = np.array(s.context().semiaxes)
+    s.run(1, dt, 0.0, noise=g.NOISE_ZERO, flags=flags)
+    c = s.context()
+    assert c.step == 1 and c.time == pytest.approx(dt)
+    assert c.bead_scale == pytest.approx(1 - 0.2 * np.exp(-dt / 1.0), rel=1e-14)
+    react = np.array(c.axial_reaction)
+    assert np.allclose(np.array(c.semiaxes), R0 + dt * 1e-4 * (react - 1e4 * R0), rtol=1e-14)
+
+
+def test_quantisation_matches_store(oracle):
+    s = g.System(oracle, 3, 1)
+    x = np.array([[0.1234567, -3.7654321, 5.00000763], [1e-6, -1e-6, 0.5], [2.0000076, 7.99999, -7.99999]])
+    s.set_positions(x)
+    q = s.positions_f32(quantize=True)[0]
+    ref = np.rint(x.astype(np.float32) * np.float32(65536)) / np.float32(65536)      # simulation_store.cc:403-407
+    assert np.array_equal(q, ref.astype(np.float32))
+
+
+def test_error_behaviour(oracle):
+    s, dt, kT, flags = build(oracle, "ab_box")
+    with pytest.raises(g.GdynError) as e:
+        s.run(1, dt, kT, spacestep=0.1)
+    assert e.value.code == 6                       # GD_EUNSUPPORTED: adaptive step
+    with pytest.raises(g.GdynError):
+        s.run(1, dt, kT, flags=g.RUN_WALL_DYNAMICS)  # no wall configured
+    with pytest.raises(g.GdynError):
+        s.add_bond_range(g.System.bond_params(g.POT_HARMONIC, 1.0), 0, s.N + 1)
+    with pytest.raises(g.GdynError):
+        s.set_pair_softcore(1.0, 1.0, p_a=3)
+    with pytest.raises(g.GdynError):
+        s.set_positions(np.full((1, s.N, 3), np.nan))
+    with pytest.raises(g.GdynError):
+        g.System(oracle, 0, 1)

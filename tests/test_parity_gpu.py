@@ -1,0 +1,228 @@
+"""Parity of the HIP path (through the C-ABI of libgdyn) against the CPU oracle, the committed golden
+vectors, and size-independent properties at the BASELINE.json sizes.  Tolerances are the fp32
+tolerances stated in tests/util.py / DESIGN.md."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from util import (CASES, ENERGY_RTOL, FORCE_RTOL, POS_ATOL_1STEP, POS_ATOL_20STEP, TERMS, build, g, wl)
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "golden_small.npz"))
+SEED = 20220101
+PATHS = {"generic": 1, "tiled": 2}
+
+
+def _paths(name):
+    # the LDS-tiled path serves open boxes; periodic systems use the global-gather path
+    return ["generic", "tiled"] if name in ("genome", "spindle") else ["generic"]
+
+
+def _cases_paths():
+    return [(n, p) for n in CASES for p in _paths(n)]
+
+
+@pytest.mark.parametrize("name,path", _cases_paths())
+def test_forces_and_energies_vs_golden(hip, name, path):
+    s, *_ = build(hip, name)
+    s.set_tuning(kernel_path=PATHS[path])
+    scale = np.abs(GOLD[f"{name}/F_all"]).max()
+    escale = sum(abs(GOLD[f"{name}/E_{t}"][0]) for t in TERMS if t != "all")
+    for t, m in TERMS.items():
+        F = s.forces(m)
+        assert np.abs(F - GOLD[f"{name}/F_{t}"]).max() <= FORCE_RTOL * scale, t
+        assert abs(s.energy(m)[0] - GOLD[f"{name}/E_{t}"][0]) <= ENERGY_RTOL * escale, t
+
+
+@pytest.mark.parametrize("name,path", _cases_paths())
+def test_trajectories_vs_golden(hip, name, path):
+    _, _, dt, kT, flags = CASES[name]
+    for tag, steps, noise, temp, tol in (("philox1", 1, g.NOISE_PHILOX, kT, POS_ATOL_1STEP),
+                                         ("philox10", 10, g.NOISE_PHILOX, kT, POS_ATOL_20STEP),
+                                         ("zero20", 20, g.NOISE_ZERO, 0.0, POS_ATOL_20STEP)):
+        s, *_ = build(hip, name)
+        s.set_tuning(kernel_path=PATHS[path])
+        s.begin_phase()
+        s.run(steps, dt, temp, seed=SEED, noise=noise, flags=flags)
+        scale = max(1.0, np.abs(GOLD[f"{name}/x0"]).max() / 8)          # fp32 ulp grows with |x| (1 kb box ~ 40 units)
+        assert np.abs(s.positions() - GOLD[f"{name}/x_{tag}"]).max() <= tol * scale, tag
+        c = s.context()
+        ref = GOLD[f"{name}/ctx_{tag}"]
+        assert c.step == int(ref[0]) and c.time == pytest.approx(ref[1], rel=1e-12)
+        assert c.bead_scale == pytest.approx(ref[2], rel=1e-12) and c.bond_scale == pytest.approx(ref[3], rel=1e-12)
+        if name == "genome":
+            assert np.allclose(np.array(c.semiaxes), ref[4:7], rtol=0, atol=1e-8)
+            assert np.allclose(np.array(c.axial_reaction), ref[7:10], rtol=2e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_injected_noise_trajectory(hip, name):
+    _, _, dt, kT, flags = CASES[name]
+    s, *_ = build(hip, name)
+    z = np.random.default_rng(SEED).normal(size=(5, 1, s.N, 3))
+    s.begin_phase()
+    s.run(5, dt, kT, noise=g.NOISE_HOST, host_noise=z, flags=flags)
+    scale = max(1.0, np.abs(GOLD[f"{name}/x0"]).max() / 8)
+    assert np.abs(s.positions() - GOLD[f"{name}/x_host5"]).max() <= POS_ATOL_20STEP * scale
+
+
+@pytest.mark.parametrize("name", ["genome", "chromatin_1kb"])
+def test_replica_batch_matches_oracle(hip, oracle, name):
+    """R replicas in one launch: each replica is its own trajectory with its own Philox stream and context."""
+    _, _, dt, kT, flags = CASES[name]
+    sh, *_ = build(hip, name, n_replicas=3)
+    so, *_ = build(oracle, name, n_replicas=3)
+    x0 = so.positions()
+    x0[1] += 0.01 * np.random.default_rng(1).normal(size=x0[1].shape)     # make the replicas differ
+    for s in (sh, so):
+        s.set_positions(x0)
+        s.begin_phase()
+    scale = np.abs(so.forces()).max()
+    assert np.abs(sh.forces() - so.forces()).max() <= FORCE_RTOL * scale
+    for s in (sh, so):
+        s.run(6, dt, kT, seed=SEED, flags=flags)
+    xh, xo = sh.positions(), so.positions()
+    assert np.abs(xh - xo).max() <= POS_ATOL_20STEP * max(1.0, np.abs(xo).max() / 8)
+    assert np.abs(xo[0] - xo[2]).max() > 1e-4            # same start, different replica index => different noise
+    for r in range(3):
+        assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), atol=1e-8)
+
+
+@pytest.mark.parametrize("box", [None, (2.9,) * 3, (0.9, 1.3, 2.9)])
+def test_neighbor_search_pair_set(hip, oracle, box):
+    """md::neighbor_searcher::search: the pair SET is exact (beads on cell/box boundaries, aliasing small grids)."""
+    rng = np.random.default_rng(5)
+    n = 1500
+    x = rng.random((n, 3)) * (np.array(box) if box else 3.0) * (1.3 if box else 1.0)
+    x[:50] = np.round(x[:50] / 0.3) * 0.3
+    x = x.astype(np.float32).astype(np.float64)            # identical fp32-representable inputs on both sides
+    sh, so = g.System(hip, n, 1, box=box), g.System(oracle, n, 1, box=box)
+    for s in (sh, so):
+        s.set_positions(x)
+    ph = {tuple(p) for p in sh.search_pairs(0.3)}
+    po = {tuple(p) for p in so.search_pairs(0.3)}
+    diff = ph ^ po
+    # a pair may differ only if its distance is within fp32 rounding of the cutoff
+    for i, j in diff:
+        d = x[i] - x[j]
+        if box:
+            d -= np.array(box) * np.rint(d / np.array(box))
+        assert abs(np.linalg.norm(d) - 0.3) < 1e-6
+    assert len(ph) > 100
+
+
+def test_quantised_snapshot(hip):
+    s = g.System(hip, 3, 1)
+    x = np.array([[0.1234567, -3.7654321, 5.00000763], [1e-6, -1e-6, 0.5], [2.0000076, 7.99999, -7.99999]])
+    s.set_positions(x)
+    ref = np.rint(x.astype(np.float32) * np.float32(65536)) / np.float32(65536)
+    assert np.array_equal(s.positions_f32(quantize=True)[0], ref.astype(np.float32))
+    assert np.array_equal(s.positions_f32()[0], x.astype(np.float32))
+
+
+def test_edge_cases(hip, oracle):
+    # a single bead, beads on top of each other, an empty bond range, a bead at the wall centre
+    for lib in (hip, oracle):
+        s = g.System(lib, 1, 1)
+        s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
+        s.set_ellipsoid_wall(2.0, 0.3, 2.0, 0.24, 5.0, 5.0, 5000.0, (1e4,) * 3, 1e-4, (2.0,) * 3)
+        s.add_bond_range(g.System.bond_params(g.POT_HARMONIC, 1.0), 0, 1)     # no bond in a 1-bead range
+        s.set_positions(np.zeros((1, 1, 3)))
+        assert np.all(s.forces() == 0) and s.energy()[0] == 0
+        s.run(3, 1e-5, 1.0, seed=1)
+        assert np.isfinite(s.positions()).all()
+    out = []
+    for lib in (hip, oracle):
+        s = g.System(lib, 4, 1)
+        s.set_pair_softcore(2.0, 0.3, 2.0, 0.24, mix=False)
+        s.add_bond_range(g.System.bond_params(g.POT_SPRING, 10.0, 0.2), 0, 4)
+        s.set_positions(np.array([[0.0, 0, 0], [0.0, 0, 0], [0.1, 0, 0], [5.0, 5, 5]]))   # coincident beads: r = 0
+        out.append((s.forces(), s.energy()))
+    assert np.allclose(out[0][0], out[1][0], atol=1e-4) and np.allclose(out[0][1], out[1][1], rtol=1e-6)
+
+
+def test_errors_match_oracle(hip):
+    s, dt, kT, flags = build(hip, "ab_box")
+    with pytest.raises(g.GdynError) as e:
+        s.run(1, dt, kT, spacestep=0.1)
+    assert e.value.code == 6
+    with pytest.raises(g.GdynError):
+        s.run(1, dt, kT, flags=g.RUN_WALL_DYNAMICS)
+    with pytest.raises(g.GdynError):
+        s.run(1, dt, kT, noise=g.NOISE_MT19937)          # the reference's RNG class exists only in the oracle
+    with pytest.raises(g.GdynError):
+        s.add_bond_range(g.System.bond_params(g.POT_HARMONIC, 1.0), 0, s.N + 1)
+    with pytest.raises(g.GdynError):
+        s.set_positions(np.full((1, s.N, 3), np.inf))
+
+
+def test_rollback_is_transparent(hip):
+    """A deliberately too-long rebuild interval violates the Verlet skin; the chunk is rolled back and re-run,
+    and the trajectory still matches the safe one to rounding."""
+    out = []
+    for interval in (1, 60):
+        s, dt, kT, flags = build(hip, "genome")
+        s.set_tuning(rebuild_interval=interval, adapt_interval=0)
+        s.begin_phase()
+        s.run(60, dt, kT, seed=SEED, flags=flags)
+        out.append((s.positions(), s.context().rollbacks))
+    assert out[1][1] >= 1 and out[0][1] == 0
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-4
+
+
+# ---------------------------------------------------------------- BASELINE sizes
+
+def test_full_size_genome_properties(hip):
+    """S-genome-30k x 2 replicas: generic and tiled paths agree, internal forces sum to zero, the pair set is
+    the KD-tree pair set, and T=0 dynamics is a descent (energy never increases)."""
+    from scipy.spatial import cKDTree
+    s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=2)
+    x0 = s.positions()
+    internal = g.TERM_PAIR | g.TERM_BOND
+    res = {}
+    for path in ("generic", "tiled"):
+        s.set_tuning(kernel_path=PATHS[path])
+        res[path] = (s.forces(), s.forces(internal), s.energy())
+    scale = np.abs(res["generic"][0]).max()
+    assert np.abs(res["generic"][0] - res["tiled"][0]).max() <= 1e-5 * scale
+    assert np.allclose(res["generic"][2], res["tiled"][2], rtol=1e-6)
+    Fi = res["tiled"][1]
+    assert np.abs(Fi.sum(axis=1)).max() <= 2e-6 * np.abs(Fi).sum(axis=(1, 2)).max()
+    pairs = {tuple(p) for p in s.search_pairs(0.3, replica=1)}
+    ref = {tuple(sorted(p)) for p in cKDTree(x0[1].astype(np.float32).astype(np.float64)).query_pairs(0.3)}
+    assert len(pairs ^ ref) <= 3 and len(ref) > 100000           # only pairs within fp32 rounding of the cutoff may differ
+    s.set_tuning(kernel_path=0)
+    s.begin_phase()
+    e = [s.energy().sum()]
+    for _ in range(4):
+        s.run(25, 1e-5, 0.0, noise=g.NOISE_ZERO)
+        e.append(s.energy().sum())
+    assert all(b < a for a, b in zip(e, e[1:]))
+
+
+def test_full_size_1kb_properties(hip):
+    """S-1kb-250k (periodic): internal forces sum to zero, noise has the right variance, descent at T=0."""
+    s, info = wl.chromatin_1kb(hip, n_beads=250000)
+    F = s.forces(g.TERM_PAIR | g.TERM_BOND | g.TERM_BEND | g.TERM_DYNAMIC)
+    assert np.abs(F.sum(axis=1)).max() <= 2e-6 * np.abs(F).sum()
+    x0 = s.positions()
+    e0 = s.energy()[0]
+    s.run(10, 1e-4, 0.0, noise=g.NOISE_ZERO)
+    assert s.energy()[0] < e0
+    s.set_positions(x0)
+    sf = g.System(hip, 250000, 1)                     # free beads: MSD = 6 mu kT t
+    sf.set_positions(np.zeros((250000, 3)))
+    sf.run(20, 1e-3, 0.5, seed=3)
+    assert (sf.positions()[0] ** 2).sum(axis=1).mean() == pytest.approx(6 * 0.5 * 20 * 1e-3, rel=0.01)
+
+
+def test_philox_stream_is_counter_based(hip):
+    """Noise depends only on (seed, bead, step, replica): running 10 steps equals 4 + 6 steps."""
+    a, dt, kT, flags = build(hip, "spindle")
+    b, *_ = build(hip, "spindle")
+    a.begin_phase(); b.begin_phase()
+    a.run(10, dt, kT, seed=9)
+    b.run(4, dt, kT, seed=9); b.run(6, dt, kT, seed=9)
+    assert np.abs(a.positions() - b.positions()).max() <= 2e-5
