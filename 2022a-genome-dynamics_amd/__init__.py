@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBGDYN_PATH = os.path.join(_HERE, "csrc", "libgdyn.so")
+LIBGDYN_PATH = os.path.join(_HERE, "csrc", os.environ.get("GDYN_LIB", "libgdyn.so"))
 
 GD_BOX_OPEN, GD_BOX_PERIODIC = 0, 1
 POT_HARMONIC, POT_SPRING, POT_SEMISPRING, POT_SOFTCORE = 0, 1, 2, 3

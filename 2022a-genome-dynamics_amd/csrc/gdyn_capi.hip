@@ -99,6 +99,7 @@ struct gd_system {
     // tuning / cadence
     double skin = 0.5;
     uint32_t K = 4, adapt = 1, use_graph = 0;
+    uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
     float rv = 0;
     uint64_t rebuilds = 0, rollbacks = 0;
@@ -110,10 +111,11 @@ struct gd_system {
     DevBuf<unsigned> badj_o; DevBuf<int4> chain_o; DevBuf<BondType> btab;
     // device: per slot
     DevBuf<float4> pos[2], xb, fout, snap;
-    DevBuf<unsigned> orig[2], slot_of, cell_id, rank, cell_cnt, cell_start, nbr, ncnt, badj, flags, cell_s;
+    DevBuf<unsigned> orig[2], slot_of, cell_id, rank, cell_cnt, cell_start, nbr, meta, badj, flags, cell_s;
     DevBuf<unsigned short> nbr16; DevBuf<TileDesc> tiles;
     DevBuf<float> bbox;
-    DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<unsigned char> psmask, bdeg; DevBuf<int4> chain;
+    DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<int4> chain;
+    float mob_uniform = -1.f;
     DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part; DevBuf<double> epart;
     DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
     int ocur = 0;   // which orig[] buffer is current
@@ -161,10 +163,9 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     }
     ok = ok && s->xb.resize(RNp) == hipSuccess && s->slot_of.resize(RN) == hipSuccess && s->cell_id.resize(RNp) == hipSuccess &&
          s->rank.resize(RNp) == hipSuccess && s->cell_cnt.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess &&
-         s->cell_start.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess && s->ncnt.resize(RNp) == hipSuccess &&
+         s->cell_start.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess && s->meta.resize(RNp) == hipSuccess &&
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
-         s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->bendE.resize(RNp) == hipSuccess &&
-         s->psmask.resize(RNp) == hipSuccess && s->bdeg.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
+         s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->react_part.resize((size_t)s->R * s->nblk) == hipSuccess && s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->lcount_d.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess;
@@ -516,9 +517,12 @@ static int finalize_topology(gd_system *s)
     HIPCHK(hipMemcpy(s->chain_o.p, chain.data(), N * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->btab.p, bt.data(), bt.size() * sizeof(BondType), hipMemcpyHostToDevice));
     const size_t RNp = (size_t)s->R * s->Np;
-    if (WB != s->WB || !s->badj.p) { HIPCHK(s->badj.resize((size_t)std::max(WB, 1u) * RNp)); }
-    if (has_bend && !s->chain.p) HIPCHK(s->chain.resize(RNp));
-    s->WB = WB; s->has_bend = has_bend; s->has_bonds = !all.empty();
+    const uint32_t WBp = std::max((WB + 3u) & ~3u, 4u);      // adjacency width in entries, chunks of 4
+    if (WBp != s->WB || !s->badj.p) { HIPCHK(s->badj.resize((size_t)WBp * RNp)); }
+    if (has_bend && !s->chain.p) { HIPCHK(s->chain.resize(RNp)); HIPCHK(s->bendE.resize(RNp)); }
+    s->WB = WBp; s->has_bend = has_bend; s->has_bonds = !all.empty();
+    s->mob_uniform = (float)s->mob[0];
+    for (uint32_t i = 1; i < N; i++) if ((float)s->mob[i] != s->mob_uniform) { s->mob_uniform = -1.f; break; }
     s->topo_dirty = false; s->list_valid = false;
     return GD_OK;
 }
@@ -546,11 +550,11 @@ static void fill_common(gd_system *s, StepParams &p)
     p.periodic = s->box_kind == GD_BOX_PERIODIC;
     for (int k = 0; k < 3; k++) { p.box[k] = (float)s->box[k]; p.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
     p.pos_in = s->pos[s->pcur].p; p.pos_out = s->pos[s->pcur ^ 1].p; p.xb = s->xb.p; p.orig = s->orig[s->ocur].p;
-    p.ab = s->ab.p; p.mob = s->mobs.p; p.bendE = s->bendE.p; p.psmask = s->psmask.p;
+    p.ab = s->ab.p; p.mob = s->mobs.p; p.bendE = s->bendE.p; p.mob_uniform = s->mob_uniform; p.WB = s->WB;
     p.nbr = s->nbr.p; p.nbr16 = s->nbr16.p; p.tiles = s->tiles.p; p.tiled = s->list_tiled ? 1 : 0; p.packed_ab = s->packed_ab ? 1 : 0;
     p.cpb = s->cpb; p.tile_cap = s->tile_cap;
-    p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? 1 : 0;
-    p.ncnt = s->ncnt.p; p.W = s->W; p.badj = s->badj.p; p.bdeg = s->bdeg.p; p.chain = s->chain.p;
+    p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
+    p.meta = s->meta.p; p.W = s->W; p.badj = s->badj.p; p.chain = s->chain.p;
     p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.react_part = s->react_part.p; p.flags = s->flags.p;
     if (s->has_pair) {
         const gd_pair_softcore &q = s->pair;
@@ -606,9 +610,10 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.bbox = s->bbox.p; b.grid = s->grid.p;
     b.ab_o = s->ab_o.p; b.mob_o = s->mob_o.p; b.bendE_o = s->bendE_o.p; b.psmask_o = s->psmask_o.p;
     b.badj_o = s->badj_o.p; b.bdeg_o = s->bdeg_o.p; b.chain_o = s->has_bend ? s->chain_o.p : nullptr; b.WB = s->WB;
-    b.ab = s->ab.p; b.mob = s->mobs.p; b.bendE = s->bendE.p; b.psmask = s->psmask.p; b.badj = s->badj.p; b.bdeg = s->bdeg.p;
+    b.ab = s->ab.p; b.mob = s->mobs.p; b.bendE = s->bendE.p; b.badj = s->badj.p; b.has_bend = s->has_bend ? 1 : 0;
+    b.mob_is_uniform = s->mob_uniform >= 0.f ? 1 : 0;
     b.chain = s->chain.p; b.nbr = (with_list && !tiled) ? s->nbr.p : nullptr; b.nbr16 = tiled ? s->nbr16.p : nullptr;
-    b.ncnt = s->ncnt.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
+    b.meta = s->meta.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p;
     gd_launch_build(b, s->stream);
@@ -739,7 +744,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     int64_t done = 0;
     while (done < run->steps) {
         // ---- one verified chunk
-        const int64_t chunk = std::min<int64_t>(run->steps - done, std::max<int64_t>(256, 32ll * s->K));
+        const int64_t chunk = std::min<int64_t>(run->steps - done, std::min<int64_t>(256, std::max<int64_t>(32, 16ll * s->K)));
         // snapshot for rollback: positions in bead order + context
         gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->snap.p, s->N, s->Np, s->R, 0, s->stream);
         const std::vector<DevCtx> snap_ctx = s->hctx;
@@ -809,7 +814,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 if (s->K == 1) {
                     if (s->skin > 8) return fail(GD_ESTATE, "gd_run: Verlet skin cannot cover one step (timestep too large?)");
                     s->skin *= 1.5;
-                } else s->K = std::max(1u, s->K / 2);
+                } else { s->K_bad = s->K; s->K_bad_ttl = 64; s->K = std::max(1u, s->K - std::max(1u, s->K / 4)); }
             }
             s->timing.step_launches -= std::min<uint64_t>(s->timing.step_launches, (uint64_t)chunk);
             continue;
@@ -833,10 +838,11 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             if (lim > 0 && d > 0) {
                 // displacement grows ~ sqrt(steps): aim at 60% of the skin at the end of an interval
                 const double ratio = d / lim;
-                double knew = (double)s->K * (0.6 / ratio) * (0.6 / ratio);
+                double knew = (double)s->K * (0.7 / ratio) * (0.7 / ratio);
                 knew = std::min(knew, 2.0 * s->K + 1);
                 s->K = (uint32_t)std::max(1.0, std::min(200.0, std::floor(knew)));
             } else if (d == 0) s->K = std::min(200u, s->K * 2);
+            if (s->K_bad_ttl > 0) { s->K_bad_ttl--; if (s->K >= s->K_bad) s->K = std::max(1u, s->K_bad - 1); }
         }
         done += chunk;
     }
@@ -894,7 +900,8 @@ extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *
     s->list_valid = false;   // the force list was overwritten with the search radius
     const uint32_t N = s->N, W = s->W, NC = W / 4;
     std::vector<unsigned> cnt(N), org(N);
-    HIPCHK(hipMemcpy(cnt.data(), s->ncnt.p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt.data(), s->meta.p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (auto &c : cnt) c >>= 16;
     HIPCHK(hipMemcpy(org.data(), s->orig[s->ocur].p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
     // generic list layout: chunk c (4 slots) of bead g is uint4 #((g/64)*NC + c)*64 + g%64
     const size_t wave0 = ((size_t)r * s->Np) / 64, nwaves = s->Np / 64;

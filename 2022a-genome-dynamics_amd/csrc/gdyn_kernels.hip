@@ -17,6 +17,10 @@
 
 #include "gdyn_types.h"
 
+#ifndef GD_ABL
+#define GD_ABL 0   // timing-only ablation builds (never shipped): 1 = no list stores, 2 = no sweep, 3 = no sweep + no bond re-map, 4 = 3 + no tile staging
+#endif
+
 #define TERM_PAIR 1u
 #define TERM_BOND 2u
 #define TERM_BEND 4u
@@ -228,7 +232,8 @@ struct CtxF {
 
 // TILED: the block first stages its LDS tile (its own 256 slots + all slots of the adjacent
 // cells, 9 contiguous slot ranges, TileDesc) with coalesced loads; pair-list entries are 16-bit
-// indices into that tile, so the neighbour gather is an LDS read.  PK=1: softcore<2,3>+<8,3>.
+// indices into that tile, so the neighbour gather is an LDS read.  PK=1/2: softcore<2,3>+<8,3>
+// with / without AB mixing (compile-time), PK=0: runtime powers.
 template <int MODE, bool PERIODIC, bool TILED, int PK>
 __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 {
@@ -244,6 +249,26 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     const size_t rbase = (size_t)r * p.Np;
     const float4 *__restrict__ rpos = p.pos_in + rbase;
 
+    // every independent per-bead load is issued up front, ahead of the tile staging and the barrier,
+    // so their latencies overlap (the kernel is latency-bound, not ALU-bound)
+    const unsigned slot = blk * GD_BLOCK + tid;
+    const bool valid = slot < p.N;
+    const size_t g = rbase + slot;
+    const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
+    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(g >> 6) * NCL * 64 + (g & 63);
+    const uint4 *__restrict__ adj = (const uint4 *)p.badj + (size_t)(g >> 6) * NCB * 64 + (g & 63);
+    float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f), x0 = xi4;
+    unsigned meta = 0, oid = 0;
+    uint4 adj0 = make_uint4(0, 0, 0, 0), qa = adj0, qb = adj0;
+    float mu = p.mob_uniform;
+    if (valid) {
+        xi4 = p.pos_in[g];
+        meta = p.meta[g];
+        if (MODE != GD_MODE_ENERGY) oid = p.orig[g];
+        if (MODE == GD_MODE_STEP) { x0 = p.xb[g]; if (p.mob_uniform < 0.f) mu = p.mob[g]; }
+        if (p.has_bonds) adj0 = adj[0];
+        if (p.pair.enabled) { qa = lst[0]; if (!TILED) qb = lst[64]; }
+    }
     for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
     if (TILED) {
         const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
@@ -267,9 +292,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     }
     __syncthreads();
 
-    const unsigned slot = blk * GD_BLOCK + tid;
-    const bool valid = slot < p.N;
-    const size_t g = rbase + slot;
     const unsigned mask = (MODE == GD_MODE_STEP) ? 63u : p.term_mask;
 
     float3 F = make_float3(0.f, 0.f, 0.f);
@@ -278,10 +300,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     float disp2 = 0.f;
 
     if (valid) {
-        const float4 xi4 = p.pos_in[g];
         const float3 xi = make_float3(xi4.x, xi4.y, xi4.z);
         const float2 *__restrict__ rab = p.ab + rbase;
-        const float2 abi = p.ab[g];
+        const float2 abi = p.packed_ab ? unpack_ab(xi4.w) : p.ab[g];
 
         // ---- non-bonded pairs over the Verlet list (a3, a5)
         if (p.pair.enabled && (mask & TERM_PAIR)) {
@@ -290,12 +311,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             const float inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f, inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
             const float cut = p.pair.cutoff * sc, cut2 = cut * cut;
             const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb = 24.0f * p.pair.eps_b * inv_sb2;
-            const unsigned cnt = p.ncnt[g];
+            const unsigned cnt = meta >> 16;
             // Pair lists are stored in chunks of 16 bytes per bead, wave-interleaved:
             // chunk c of bead g is uint4 #((g/64)*NC + c)*64 + g%64  (one coalesced 1 KiB read per wave).
             // Tiled: 8 x u16 tile indices per chunk; generic: 4 x u32 slots per chunk.
-            const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(g >> 6) * (TILED ? p.W / 8 : p.W / 4) * 64 + (g & 63);
-            const bool mix = p.pair.mix != 0;
+            const bool mix = (PK == 1) || (PK == 0 && p.pair.mix != 0);
             // The list is padded to a multiple of GD_UNROLL with the bead's own index (zero
             // displacement => zero force), so every batch issues its index loads and its
             // neighbour reads together and the loop body has no bounds test.
@@ -303,12 +323,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
                 unsigned jj[GD_UNROLL];
                 float4 xjv[GD_UNROLL];
+                const uint4 q = qa, q0 = qa, q1 = qb;
+                if (k0 + GD_UNROLL < cntp) {
+                    if (TILED) qa = lst[(size_t)(k0 / 8 + 1) * 64];
+                    else { qa = lst[(size_t)(k0 / 4 + 2) * 64]; qb = lst[(size_t)(k0 / 4 + 3) * 64]; }
+                }
                 if (TILED) {
-                    const uint4 q = lst[(size_t)(k0 / 8) * 64];
                     jj[0] = q.x & 0xffffu; jj[1] = q.x >> 16; jj[2] = q.y & 0xffffu; jj[3] = q.y >> 16;
                     jj[4] = q.z & 0xffffu; jj[5] = q.z >> 16; jj[6] = q.w & 0xffffu; jj[7] = q.w >> 16;
                 } else {
-                    const uint4 q0 = lst[(size_t)(k0 / 4) * 64], q1 = lst[(size_t)(k0 / 4 + 1) * 64];
                     jj[0] = q0.x; jj[1] = q0.y; jj[2] = q0.z; jj[3] = q0.w; jj[4] = q1.x; jj[5] = q1.y; jj[6] = q1.z; jj[7] = q1.w;
                 }
 #pragma unroll
@@ -321,8 +344,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                     if (PERIODIC) d = min_image(d, p.box, p.inv_box);
                     const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
                     float wa = 1.0f, wb = 1.0f;
-                    if (PK == 1) {
-                        if (mix) {
+                    if (PK != 0) {
+                        if (PK == 1) {
                             const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
                             wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y);
                         }
@@ -347,7 +370,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             if (MODE == GD_MODE_STEP) {
                 // Verlet-skin check: the list is complete for this force evaluation iff every
                 // bead moved less than (rv - cutoff)/2 since the build.
-                const float4 x0 = p.xb[g];
                 const float dx = xi.x - x0.x, dy = xi.y - x0.y, dz = xi.z - x0.z;
                 disp2 = dx * dx + dy * dy + dz * dz;
                 const float lim = 0.5f * (p.rv - cut);
@@ -357,10 +379,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 
         // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
         if (p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
-            const unsigned deg = p.bdeg[g];
-            const unsigned *__restrict__ col = p.badj + g;
+            const unsigned deg = meta & 0xffu;
+            uint4 aq = adj0;
             for (unsigned k = 0; k < deg; k++) {
-                const unsigned ent = col[(size_t)k * p.stride];
+                if (k && (k & 3u) == 0) aq = adj[(size_t)(k >> 2) * 64];
+                const unsigned ent = (k & 3u) == 0 ? aq.x : (k & 3u) == 1 ? aq.y : (k & 3u) == 2 ? aq.z : aq.w;
                 const unsigned j = ent & GD_ADJ_MASK;
                 const BondType bt = s_bt[(ent >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1)];
                 if (!(mask & (unsigned)bt.term)) continue;
@@ -422,7 +445,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 
         // ---- point sources (a8)
         if (p.nps > 0 && (mask & TERM_POINT)) {
-            const unsigned pm = p.psmask[g];
+            const unsigned pm = (meta >> 8) & 0xffu;
             for (int s = 0; s < p.nps; s++) {
                 if (!((pm >> s) & 1u)) continue;
                 const float3 d = make_float3(xi.x - p.ps[s].p[0], xi.y - p.ps[s].p[1], xi.z - p.ps[s].p[2]);
@@ -474,10 +497,10 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 
         if (MODE == GD_MODE_STEP) {
             // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
-            const float mu_dt = p.mob[g] * p.dt;
+            const float mu_dt = mu * p.dt;
             float3 z = make_float3(0.f, 0.f, 0.f);
             if (p.kT > 0.f) {
-                const unsigned o = p.orig[g];
+                const unsigned o = oid;
                 if (p.noise_mode == NOISE_PHILOX) z = philox_normal3(p.seed, o, s_ctx.step + 1, r);
                 else if (p.noise_mode == NOISE_HOST) {
                     const float *h = p.host_noise + ((size_t)r * p.N + o) * 3;
@@ -488,7 +511,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             p.pos_out[g] = make_float4(xi.x + mu_dt * F.x + sg * z.x, xi.y + mu_dt * F.y + sg * z.y,
                                        xi.z + mu_dt * F.z + sg * z.z, xi4.w);
         } else if (MODE == GD_MODE_FORCE) {
-            p.fout[(size_t)r * p.N + p.orig[g]] = make_float4(F.x, F.y, F.z, 0.f);
+            p.fout[(size_t)r * p.N + oid] = make_float4(F.x, F.y, F.z, 0.f);
         }
     }
 
@@ -548,12 +571,13 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
             once = true;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         }
     }
 #define L(PER, TIL, PK) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK>), grid, block, lds, st, p)
-    if (p.periodic) { if (p.pk) L(true, false, 1); else L(true, false, 0); }
-    else if (p.tiled) { if (p.pk) L(false, true, 1); else L(false, true, 0); }
-    else { if (p.pk) L(false, false, 1); else L(false, false, 0); }
+    if (p.periodic) { if (p.pk == 1) L(true, false, 1); else if (p.pk == 2) L(true, false, 2); else L(true, false, 0); }
+    else if (p.tiled) { if (p.pk == 1) L(false, true, 1); else if (p.pk == 2) L(false, true, 2); else L(false, true, 0); }
+    else { if (p.pk == 1) L(false, false, 1); else if (p.pk == 2) L(false, false, 2); else L(false, false, 0); }
 #undef L
 }
 
@@ -720,11 +744,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
     p.orig_out[gn] = o;
     p.cell_s[gn] = c;
     p.slot_of[(size_t)r * p.N + o] = ns;
-    p.ab[gn] = ab;
-    p.mob[gn] = p.mob_o[o];
-    p.bendE[gn] = p.bendE_o[o];
-    p.psmask[gn] = p.psmask_o[o];
-    p.bdeg[gn] = p.bdeg_o[o];
+    if (!p.packed_ab) p.ab[gn] = ab;
+    if (!p.mob_is_uniform) p.mob[gn] = p.mob_o[o];
+    if (p.has_bend) p.bendE[gn] = p.bendE_o[o];
 }
 
 // One thread per block of slots: the (up to 9) slot ranges of its LDS tile. A block covers the contiguous
@@ -742,27 +764,38 @@ __global__ void k_tiles(const BuildParams p)
     const int c0 = (int)p.cell_s[rbase + first], c1 = (int)p.cell_s[rbase + last];
     TileDesc td;
     // the 9 (dz,dy) cell ranges come out ordered by their first cell; merge the overlapping ones
-    int mlo[GD_TILE_RANGES], mhi[GD_TILE_RANGES], nm = 0;
+    int mlo[GD_TILE_RANGES], mhi[GD_TILE_RANGES], klo[GD_TILE_RANGES], kin[GD_TILE_RANGES], nm = 0;
     for (int k = 0; k < GD_TILE_RANGES; k++) {
         const int dz = k / 3 - 1, dy = k % 3 - 1;
         const int off = (dz * gp.nc[1] + dy) * gp.nc[0];
         const int lo = max(c0 + off - 1, 0), hi = min(c1 + off + 1, gp.ncell - 1);
+        klo[k] = lo; kin[k] = -1;
         if (lo > hi) continue;
         if (nm > 0 && lo <= mhi[nm - 1] + 1) mhi[nm - 1] = max(mhi[nm - 1], hi);
         else { mlo[nm] = lo; mhi[nm] = hi; nm++; }
+        kin[k] = nm - 1;
     }
     unsigned total = 0;
+    bool truncated = false;
     for (int k = 0; k < GD_TILE_RANGES; k++) {
         unsigned st = 0, len = 0;
         if (k < nm) { st = cs[mlo[k]]; len = cs[mhi[k] + 1] - st; }
         if (total + len > p.tile_cap) {   // does not fit the LDS budget: flag, host rolls back and re-plans
             p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
             atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total + len);
-            len = 0;
+            len = 0; truncated = true;
         }
         td.start[k] = st; td.len[k] = (unsigned short)len; td.base[k] = (unsigned short)total;
         total += len;
     }
+    for (int k = 0; k < GD_TILE_RANGES; k++) {
+        td.kstart[k] = 0xffffffffu; td.kbase[k] = 0;
+        if (kin[k] >= 0 && !truncated) {
+            const unsigned ks = cs[klo[k]];
+            td.kstart[k] = ks; td.kbase[k] = (unsigned short)(td.base[kin[k]] + (ks - td.start[kin[k]]));
+        }
+    }
+    td.nranges = truncated ? 0u : (unsigned)nm;
     td.total = total;
     atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
     p.tiles[t] = td;
@@ -775,15 +808,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
-    __shared__ TileDesc s_td;
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
     const float4 *__restrict__ rpos = p.pos_out + rbase;
-    if (TILED) {
-        if (threadIdx.x == 0) s_td = p.tiles[(size_t)r * p.nblk + blk];
-        __syncthreads();
+    TileDesc s_td;                                   // block-uniform: lives in scalar registers
+    if (TILED) s_td = p.tiles[(size_t)r * p.nblk + blk];
+    if (TILED && GD_ABL != 4) {
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
             const unsigned len = s_td.len[k], st = s_td.start[k], base = s_td.base[k];
@@ -793,22 +825,24 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     }
     unsigned cnt = 0;
     if (slot < p.N) {
+        unsigned listlen = 0;
         const unsigned o = p.orig_out[g];
         const unsigned *so = p.slot_of + (size_t)r * p.N;
         auto to_local = [&](unsigned ps, unsigned &idx) -> bool {   // slot -> tile index
 #pragma unroll
             for (int k = 0; k < GD_TILE_RANGES; k++) {
                 const unsigned d = ps - s_td.start[k];
-                if (d < s_td.len[k]) { idx = s_td.base[k] + d; return true; }
+                if (k < (int)s_td.nranges && d < s_td.len[k]) { idx = s_td.base[k] + d; return true; }
             }
             return false;
         };
         const unsigned deg = p.bdeg_o[o];
+        unsigned *__restrict__ adjw = (unsigned *)((uint4 *)p.badj + (size_t)(g >> 6) * (p.WB / 4) * 64 + (g & 63));
         for (unsigned k = 0; k < deg; k++) {
             const unsigned ent = p.badj_o[(size_t)k * p.N + o];
             unsigned ps = so[ent & GD_ADJ_MASK], idx, out = ps | (ent & ~GD_ADJ_MASK);
             if (TILED && to_local(ps, idx)) out = idx | (ent & ~GD_ADJ_MASK) | GD_ADJ_LOCAL;
-            p.badj[(size_t)k * p.stride + g] = out;
+            adjw[(size_t)(k >> 2) * 64 * 4 + (k & 3u)] = out;
         }
         if (p.chain_o) {
             const int4 c = p.chain_o[o];
@@ -828,38 +862,66 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             int cx, cy, cz;
             cell_coords<PERIODIC>(gp, xi, p.inv_box, cx, cy, cz);
             const float rv2 = p.rv * p.rv;
-            // list writer: entries are collected in registers and stored 16 bytes at a time into the
-            // wave-interleaved chunk layout k_step reads (8 x u16 tiled, 4 x u32 generic)
-            constexpr unsigned PER = TILED ? 8u : 4u, BITS = TILED ? 16u : 32u;
+            // list writer: entries go straight into the wave-interleaved 16-byte chunk layout k_step
+            // reads (8 x u16 tiled, 4 x u32 generic); a bead's 8 (4) consecutive entries share one chunk.
+            constexpr unsigned PER = TILED ? 8u : 4u;
             const unsigned NC = p.W / PER;
             uint4 *__restrict__ lst = (TILED ? (uint4 *)p.nbr16 : (uint4 *)p.nbr) + (size_t)(g >> 6) * NC * 64 + (g & 63);
-            unsigned long long lo = 0ull, hi = 0ull;
             auto push = [&](unsigned j) {
-                const unsigned nb = cnt % PER;
-                if (nb < PER / 2) lo |= (unsigned long long)j << (BITS * nb);
-                else hi |= (unsigned long long)j << (BITS * (nb - PER / 2));
-                cnt++;
-                if (cnt % PER == 0) {
-                    const unsigned c = cnt / PER - 1;
-                    if (c < NC) lst[(size_t)c * 64] = make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
-                    lo = 0ull; hi = 0ull;
+#if GD_ABL == 1
+                asm volatile("" :: "v"(j));
+                cnt++; return;
+#endif
+                if (cnt < p.W) {
+                    uint4 *c = lst + (size_t)(cnt / PER) * 64;
+                    if (TILED) ((unsigned short *)c)[cnt % PER] = (unsigned short)j;
+                    else ((unsigned *)c)[cnt % PER] = j;
                 }
+                cnt++;
             };
             if (TILED) {
                 const unsigned x_lo = (unsigned)max(cx - 1, 0), x_hi = (unsigned)min(cx + 1, gp.nc[0] - 1);
+                // all 18 row-bound loads are issued before the first sweep (memory-level parallelism)
+                unsigned rb[GD_TILE_RANGES], re[GD_TILE_RANGES];
 #pragma unroll
                 for (int k = 0; k < GD_TILE_RANGES; k++) {
                     const int zz = cz + k / 3 - 1, yy = cy + k % 3 - 1;
-                    if (zz < 0 || zz >= gp.nc[2] || yy < 0 || yy >= gp.nc[1]) continue;
+                    rb[k] = 0; re[k] = 0;
+                    if (zz < 0 || zz >= gp.nc[2] || yy < 0 || yy >= gp.nc[1] || s_td.kstart[k] == 0xffffffffu) continue;
                     const unsigned row = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0]);
-                    const unsigned b = cs[row + x_lo], e = cs[row + x_hi + 1];
-                    unsigned lb = 0;
-                    if (e <= b || !to_local(b, lb)) continue;   // empty row (or a truncated, flagged tile)
-                    const unsigned le = lb + (e - b);
-                    for (unsigned j = lb; j < le; j++) {
-                        const float4 xj = s_tile[j];
-                        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                        if (dx * dx + dy * dy + dz * dz < rv2 && (b + (j - lb)) != slot) push(j);
+                    rb[k] = cs[row + x_lo]; re[k] = cs[row + x_hi + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < GD_TILE_RANGES; k++) {
+#if GD_ABL >= 2
+                    asm volatile("" :: "v"(rb[k]), "v"(re[k]));
+                    continue;
+#endif
+                    const unsigned b = rb[k], e = re[k];
+                    if (e <= b) continue;
+                    const unsigned lb = s_td.kbase[k] + (b - s_td.kstart[k]), le = lb + (e - b);
+                    const unsigned self_l = lb + (slot - b);       // == own tile index when the bead is in this row segment
+                    // branch-free distance tests into a per-lane bit mask, then one append per set bit:
+                    // the (divergent) append code runs max-popcount times per segment, not once per candidate
+                    for (unsigned j0 = lb; j0 < le; j0 += 32) {
+                        const unsigned n = min(32u, le - j0);
+                        unsigned m = 0;
+                        for (unsigned u0 = 0; u0 < n; u0 += 4) {
+                            float4 xj[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) xj[u] = s_tile[min(j0 + u0 + u, le - 1)];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const float dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
+                                const bool acc = (u0 + u < n) & (dx * dx + dy * dy + dz * dz < rv2) & (j0 + u0 + u != self_l);
+                                m |= (acc ? 1u : 0u) << (u0 + u);
+                            }
+                        }
+                        while (m) {
+                            const unsigned bit = __ffs(m) - 1;
+                            m &= m - 1;
+                            push(j0 + bit);
+                        }
                     }
                 }
             } else {
@@ -894,13 +956,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
                 atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], found);
             }
-            p.ncnt[g] = min(found, p.W);
+            listlen = min(found, p.W);
             // pad to a multiple of GD_UNROLL (W is one) with the bead itself: zero displacement, zero force
             unsigned self = slot;
             if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = idx; }
             while (cnt % GD_UNROLL) push(self);
             cnt = found;
         }
+        p.meta[g] = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
     }
     unsigned long long c64 = min(cnt, p.W);
     for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o, 64);

@@ -6,12 +6,14 @@
 //     between slot order and the caller's bead (chain) order.
 //   * every per-slot array is replica-major with stride Np (N padded to the block size):
 //     element (replica r, slot s) is at r*Np + s.
-//   * lists are ELL, column-major: entry k of slot g is at k*(R*Np) + g (coalesced).
+//   * pair lists and bond adjacency are stored in 16-byte chunks, wave-interleaved: chunk c of slot g is
+//     uint4 #((g/64)*NC + c)*64 + g%64 -- one coalesced 1 KiB read per wave per chunk.
+//   * meta[g] = bond degree | point-source mask << 8 | pair-list length << 16.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define GD_BLOCK 256
+#define GD_BLOCK 512
 #define GD_MAX_BOND_TYPES 32
 #define GD_MAX_POINT_SOURCES 4
 #define GD_ADJ_SHIFT 26                    // bond adjacency entry = partner | type << 26 (| GD_ADJ_LOCAL)
@@ -35,6 +37,10 @@ struct TileDesc {
     unsigned short len[GD_TILE_RANGES];    // slots in the range
     unsigned short base[GD_TILE_RANGES];   // LDS index of the range's first slot
     unsigned total;                        // beads staged
+    unsigned nranges;                      // merged ranges in use
+    // per (dz,dy) row offset k: first slot of cell c0+off_k-1 and its LDS index (0xffffffff: no such row)
+    unsigned kstart[GD_TILE_RANGES];
+    unsigned short kbase[GD_TILE_RANGES];
 };
 
 struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
@@ -98,20 +104,19 @@ struct StepParams {
     const float2 *ab;
     const float *mob;
     const float4 *bendE;                // (e_last, e_mid, e_first, -) bending energies of the 3 triplets a bead is in
-    const unsigned char *psmask;
     // lists
     const unsigned *nbr;
     const unsigned short *nbr16;        // tiled path: tile-local indices
     const TileDesc *tiles;              // [R][nblk]
-    const unsigned *ncnt;
-    unsigned W;
+    const unsigned *meta;               // bdeg | psmask << 8 | list length << 16
+    unsigned W, WB;                     // list width (entries), bond adjacency width (entries, multiple of 4)
+    float mob_uniform;                  // >= 0: every bead has this mobility (mob[] is not read)
     int tiled;                          // 1: LDS-tiled path
     int pk;                             // 1: softcore<2,3> + softcore<8,3> specialisation
     int packed_ab;                      // 1: pos.w holds (a,b) as two fp16 (exactly representable)
     unsigned cpb;                       // blocks per replica per XCD (XCD-aware block mapping)
     unsigned tile_cap;                  // beads of LDS per block
-    const unsigned *badj;
-    const unsigned char *bdeg;
+    const unsigned *badj;               // chunked like the pair lists, 4 entries per chunk
     const int4 *chain;                  // slots of (i-2, i-1, i+1, i+2) or -1
     // context
     const DevCtx *ctx_in;
@@ -171,11 +176,10 @@ struct BuildParams {
     float2 *ab;
     float *mob;
     float4 *bendE;
-    unsigned char *psmask;
     unsigned *badj;
-    unsigned char *bdeg;
     int4 *chain;
-    unsigned *nbr, *ncnt;
+    unsigned *nbr, *meta;
+    int has_bend, mob_is_uniform;
     unsigned short *nbr16;
     TileDesc *tiles;
     unsigned *cell_s;                   // cell of each new slot

@@ -8,6 +8,8 @@ hip = g.load()
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
 s.begin_phase()
+EQ = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+if EQ: s.run(EQ, 1e-5, 1.0, seed=99, flags=0); s.begin_phase()
 for i in range(6):
     t0 = time.time(); tm = s.run(50, 1e-5, 1.0, seed=3, flags=3); el = time.time() - t0
     c = s.context()
