@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "gd_add_bond_pairs", "gd_set_dynamic_pairs", "gd_add_bending_range", "gd_add_point_source",
     "gd_set_ellipsoid_wall", "gd_set_scaling", "gd_get_context", "gd_begin_phase", "gd_set_context",
     "gd_run", "gd_compute_energy", "gd_compute_forces", "gd_search_pairs", "gd_set_tuning",
-    "gd_get_timing", "gd_get_stream",
+    "gd_get_timing", "gd_get_stream", "gd_debug_bench",
 ]
 
 
@@ -144,6 +144,7 @@ class Lib:
         d.gd_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
         d.gd_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         d.gd_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        d.gd_debug_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
 
     @property
     def backend(self):
@@ -324,6 +325,11 @@ class System:
         t = Timing()
         self.lib.check(self.lib.dll.gd_get_timing(self._h, C.byref(t)))
         return t
+
+    def debug_bench(self, what, n=20):
+        ms = C.c_double(0)
+        self.lib.check(self.lib.dll.gd_debug_bench(self._h, what, n, C.byref(ms)))
+        return ms.value
 
     def stream(self):
         p = C.c_void_p()

@@ -645,12 +645,12 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     }
     if (!tover && !over && s->list_tiled && need_t > 0) {
         // size the LDS tile to what the builds actually need (more resident blocks per CU)
-        const unsigned want = std::min(9728u, need_t + need_t / 6 + 64);
+        const unsigned want = std::min(9216u, need_t + need_t / 6 + 64);
         if (want > s->tile_cap || want + want / 4 < s->tile_cap) s->tile_cap = want;
     }
     if (tover) {
         const unsigned cap = need_t + need_t / 8 + 64;
-        if (cap <= 9728) s->tile_cap = cap;    // < 160 KB of LDS per CU incl. the static part
+        if (cap <= 9216) s->tile_cap = cap;    // 144 KB dynamic + static part < 160 KB of LDS per CU
         else s->tiled_ok = false;                // too dense for one tile: generic path
     }
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
@@ -916,5 +916,34 @@ extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *
             if (i < j) { if (n < cap) { pairs[2 * n] = i; pairs[2 * n + 1] = j; } n++; }
         }
     *n_pairs = n;
+    return GD_OK;
+}
+
+// ------------------------------------------------------------ micro-benchmark
+
+extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
+{
+    if (!s || !mean_ms || n < 1) return fail(GD_EINVAL, "gd_debug_bench: bad argument");
+    GDCHK(prepare(s));
+    GDCHK(ensure_fresh_list(s));
+    hipEvent_t e0 = get_event(s, 0), e1 = get_event(s, 1);
+    const float rv = list_radius(s, nullptr, 0);
+    StepParams p;
+    fill_common(s, p);
+    p.dt_d = 1e-5; p.dt = 1e-5f; p.kT = 1.0f; p.seed = 1; p.noise_mode = GD_NOISE_PHILOX; p.run_flags = 0;
+    p.ctx_out = s->ctx[s->ccur ^ 1].p;     // scratch: the current context is not replaced
+    GDCHK(clear_flags(s));
+    HIPCHK(hipEventRecord(e0, s->stream));
+    for (int i = 0; i < n; i++) {
+        if (what == 0) { GDCHK(enqueue_build(s, rv, pair_cutoff(s) > 0)); }
+        else gd_launch_step(p, GD_MODE_STEP, s->stream);
+    }
+    HIPCHK(hipEventRecord(e1, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *mean_ms = ms / n;
+    GDCHK(clear_flags(s));
     return GD_OK;
 }

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         if (p.pair.enabled) { qa = lst[0]; if (!TILED) qb = lst[64]; }
     }
     for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
-    if (TILED) {
+    if (TILED && GD_ABL != 12) {
         const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         const float2 abi = p.packed_ab ? unpack_ab(xi4.w) : p.ab[g];
 
         // ---- non-bonded pairs over the Verlet list (a3, a5)
-        if (p.pair.enabled && (mask & TERM_PAIR)) {
+        if (GD_ABL != 11 && p.pair.enabled && (mask & TERM_PAIR)) {
             const float sc = p.pair.scaled ? s_ctx.bead_scale : 1.0f;
             const float sa = p.pair.sigma_a * sc, sb = p.pair.sigma_b * sc;
             const float inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f, inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         }
 
         // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
-        if (p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
+        if (GD_ABL != 13 && p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
             const unsigned deg = meta & 0xffu;
             uint4 aq = adj0;
             for (unsigned k = 0; k < deg; k++) {
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 
         // ---- ellipsoid wall (a9): second-order nearest-surface construction
         // (5-sim-genome/src/analyze_lamina/geometry.py:13-28), conjugate form u = C/(B+sqrt(B^2-AC)).
-        if (p.wall.enabled && (mask & TERM_WALL)) {
+        if (GD_ABL != 15 && p.wall.enabled && (mask & TERM_WALL)) {
             const float ia = 1.0f / (s_ctx.semi[0] * s_ctx.semi[0]), ib = 1.0f / (s_ctx.semi[1] * s_ctx.semi[1]),
                         ic = 1.0f / (s_ctx.semi[2] * s_ctx.semi[2]);
             const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
             const float mu_dt = mu * p.dt;
             float3 z = make_float3(0.f, 0.f, 0.f);
-            if (p.kT > 0.f) {
+            if (GD_ABL != 14 && p.kT > 0.f) {
                 const unsigned o = oid;
                 if (p.noise_mode == NOISE_PHILOX) z = philox_normal3(p.seed, o, s_ctx.step + 1, r);
                 else if (p.noise_mode == NOISE_HOST) {
@@ -569,9 +569,9 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
         static bool once = false;
         if (!once) {
             once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         }
     }
 #define L(PER, TIL, PK) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK>), grid, block, lds, st, p)
@@ -690,40 +690,69 @@ template <bool PERIODIC>
 __global__ __launch_bounds__(GD_BLOCK) void k_bin(const BuildParams p)
 {
     const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
-    const unsigned slot = blk * GD_BLOCK + threadIdx.x;
-    if (slot >= p.N) return;
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63;
+    const bool valid = slot < p.N;
     const size_t g = (size_t)r * p.Np + slot;
-    const GridP gp = p.grid[r];
-    int cx, cy, cz;
-    cell_coords<PERIODIC>(gp, p.pos_in[g], p.inv_box, cx, cy, cz);
-    const unsigned c = (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx);
-    p.cell_id[g] = c;
-    p.rank[g] = atomicAdd(&p.cell_cnt[(size_t)r * (p.ncell_cap + 1) + c], 1u);
+    unsigned c = 0xffffffffu;
+    if (valid) {
+        const GridP gp = p.grid[r];
+        int cx, cy, cz;
+        cell_coords<PERIODIC>(gp, p.pos_in[g], p.inv_box, cx, cy, cz);
+        c = (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx);
+    }
+    // Slots are still nearly cell-sorted from the previous build, so equal cells sit in runs of
+    // consecutive lanes: one atomic per run (its head lane) instead of one per bead.
+    const unsigned prev = __shfl_up(c, 1, 64);
+    const bool head = lane == 0 || prev != c;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long below = hm & ((2ull << lane) - 1ull);          // heads at or below this lane
+    const unsigned head_lane = 63u - (unsigned)__clzll(below);
+    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1)) << (lane + 1);
+    const unsigned next_head = above ? (unsigned)__ffsll((long long)above) - 1u : 64u;
+    unsigned base = 0;
+    if (head && valid) base = atomicAdd(&p.cell_cnt[(size_t)r * (p.ncell_cap + 1) + c], next_head - lane);
+    base = __shfl(base, head_lane, 64);
+    if (valid) {
+        p.cell_id[g] = c;
+        p.rank[g] = base + (lane - head_lane);
+    }
 }
 
-// exclusive scan of the cell counts of one replica (one 1024-thread block per replica)
+// exclusive scan of the cell counts of one replica (one 1024-thread block per replica); the counts go
+// through LDS in coalesced tiles so that each thread can scan a contiguous run
+#define GD_SCAN_TILE 8192u
 __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
 {
+    __shared__ unsigned s_val[GD_SCAN_TILE];
     __shared__ unsigned s_sum[1024];
     const unsigned r = blockIdx.x, tid = threadIdx.x;
     const unsigned n = (unsigned)p.grid[r].ncell;
     const unsigned *cnt = p.cell_cnt + (size_t)r * (p.ncell_cap + 1);
     unsigned *start = p.cell_start + (size_t)r * (p.ncell_cap + 1);
-    const unsigned chunk = (n + 1023u) / 1024u;
-    const unsigned b = tid * chunk, e = min(b + chunk, n);
-    unsigned s = 0;
-    for (unsigned c = b; c < e; c++) s += cnt[c];
-    s_sum[tid] = s;
-    __syncthreads();
-    for (unsigned o = 1; o < 1024; o <<= 1) {
-        unsigned v = tid >= o ? s_sum[tid - o] : 0u;
+    unsigned carry = 0;
+    for (unsigned t0 = 0; t0 < n; t0 += GD_SCAN_TILE) {
+        const unsigned m = min(GD_SCAN_TILE, n - t0);
+        for (unsigned i = tid; i < m; i += 1024) s_val[i] = cnt[t0 + i];
         __syncthreads();
-        s_sum[tid] += v;
+        const unsigned per = GD_SCAN_TILE / 1024, b = tid * per;
+        unsigned s = 0;
+        for (unsigned i = 0; i < per; i++) if (b + i < m) s += s_val[b + i];
+        s_sum[tid] = s;
+        __syncthreads();
+        for (unsigned o = 1; o < 1024; o <<= 1) {
+            const unsigned v = tid >= o ? s_sum[tid - o] : 0u;
+            __syncthreads();
+            s_sum[tid] += v;
+            __syncthreads();
+        }
+        unsigned run = carry + s_sum[tid] - s;
+        for (unsigned i = 0; i < per; i++) if (b + i < m) { const unsigned v = s_val[b + i]; s_val[b + i] = run; run += v; }
+        __syncthreads();
+        for (unsigned i = tid; i < m; i += 1024) start[t0 + i] = s_val[i];
+        carry += s_sum[1023];
         __syncthreads();
     }
-    unsigned run = s_sum[tid] - s;
-    for (unsigned c = b; c < e; c++) { start[c] = run; run += cnt[c]; }
-    if (tid == 1023) start[n] = s_sum[1023];
+    if (tid == 0) start[n] = carry;
 }
 
 __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
@@ -808,13 +837,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint4 s_stage[GD_BLOCK];   // one 16-byte list chunk under construction per thread
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
     const float4 *__restrict__ rpos = p.pos_out + rbase;
-    TileDesc s_td;                                   // block-uniform: lives in scalar registers
-    if (TILED) s_td = p.tiles[(size_t)r * p.nblk + blk];
+    // block-uniform descriptor, read through a uniform pointer (scalar loads; a local copy indexed in
+    // loops would be demoted to scratch memory)
+    const TileDesc *__restrict__ tdp = p.tiles + (size_t)r * p.nblk + blk;
+#define s_td (*tdp)
     if (TILED && GD_ABL != 4) {
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
@@ -867,17 +899,13 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             constexpr unsigned PER = TILED ? 8u : 4u;
             const unsigned NC = p.W / PER;
             uint4 *__restrict__ lst = (TILED ? (uint4 *)p.nbr16 : (uint4 *)p.nbr) + (size_t)(g >> 6) * NC * 64 + (g & 63);
+            // an entry is written into the thread's LDS slot; every PER-th entry the finished chunk
+            // goes out as one 16-byte global store (2-byte scattered global stores were 25% of the build)
             auto push = [&](unsigned j) {
-#if GD_ABL == 1
-                asm volatile("" :: "v"(j));
-                cnt++; return;
-#endif
-                if (cnt < p.W) {
-                    uint4 *c = lst + (size_t)(cnt / PER) * 64;
-                    if (TILED) ((unsigned short *)c)[cnt % PER] = (unsigned short)j;
-                    else ((unsigned *)c)[cnt % PER] = j;
-                }
+                if (TILED) ((unsigned short *)&s_stage[threadIdx.x])[cnt % PER] = (unsigned short)j;
+                else ((unsigned *)&s_stage[threadIdx.x])[cnt % PER] = j;
                 cnt++;
+                if (cnt % PER == 0 && cnt <= p.W) lst[(size_t)(cnt / PER - 1) * 64] = s_stage[threadIdx.x];
             };
             if (TILED) {
                 const unsigned x_lo = (unsigned)max(cx - 1, 0), x_hi = (unsigned)min(cx + 1, gp.nc[0] - 1);
@@ -893,7 +921,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 }
 #pragma unroll
                 for (int k = 0; k < GD_TILE_RANGES; k++) {
-#if GD_ABL >= 2
+#if GD_ABL >= 2 && GD_ABL <= 4
                     asm volatile("" :: "v"(rb[k]), "v"(re[k]));
                     continue;
 #endif
@@ -976,6 +1004,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     }
 }
 
+#undef s_td
+
 void gd_launch_build(const BuildParams &p, hipStream_t st)
 {
     const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(GD_XCDS * p.cpb * p.R);
@@ -991,7 +1021,7 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
         static bool once = false;
         if (!once) {
             once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         }
         hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
         hipLaunchKernelGGL((k_fill<false, true>), gridx, block, (size_t)p.tile_cap * sizeof(float4), st, p);

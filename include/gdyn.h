@@ -264,6 +264,10 @@ typedef struct {
 } gd_timing;
 
 int gd_get_timing(gd_system *sys, gd_timing *out);
+/* Developer micro-benchmark (not part of the reference's interface): times `n` back-to-back launches of
+ * one piece of the path on the CURRENT state with HIP events, without advancing the trajectory.
+ * what = 0: full neighbour-list build; 1: step kernel (output discarded). Returns mean ms per launch. */
+int gd_debug_bench(gd_system *sys, int what, int n, double *mean_ms);
 /* Stream the handle enqueues on (hipStream_t as void*), for callers' own events. */
 int gd_get_stream(gd_system *sys, void **stream);
 

@@ -489,6 +489,7 @@ int gd_set_tuning(gd_system *s, const gd_tuning *t)
     return GD_OK;
 }
 int gd_get_timing(gd_system *s, gd_timing *o) { if (!s || !o) return fail(GD_EINVAL, "gd_get_timing: NULL"); *o = s->timing; return GD_OK; }
+int gd_debug_bench(gd_system *s, int what, int n, double *ms) { (void)s; (void)what; (void)n; (void)ms; return fail(GD_EUNSUPPORTED, "gd_debug_bench: device-only"); }
 int gd_get_stream(gd_system *s, void **st) { (void)s; if (st) *st = NULL; return GD_OK; }
 
 /* --------------------------------------------------------------- cell grid */

@@ -1,0 +1,20 @@
+"""Micro-benchmark of the build / step kernels on a fixed equilibrated snapshot (gd_debug_bench)."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+g = importlib.import_module("2022a-genome-dynamics_amd")
+wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
+hip = g.load()
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+EQ = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+snap = f"/tmp/snap_{R}_{EQ}.npy"
+s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
+if os.path.exists(snap):
+    s.set_positions(np.load(snap))
+else:
+    s.begin_phase(); s.run(EQ, 1e-5, 1.0, seed=99, flags=0); np.save(snap, s.positions())
+s.begin_phase()
+s.run(8, 1e-5, 1.0, seed=3, flags=3)
+c = s.context()
+print(f"lib {os.environ.get('GDYN_LIB','libgdyn.so')}: build {s.debug_bench(0, 20)*1e3:.1f} us  step {s.debug_bench(1, 40)*1e3:.1f} us   L/bead {c.list_entries/30000:.1f} K {c.rebuild_interval}")
