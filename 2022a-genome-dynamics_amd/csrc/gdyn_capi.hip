@@ -97,7 +97,7 @@ struct gd_system {
     uint32_t cpb = 1, tile_cap = 3072;
 
     // tuning / cadence
-    double skin = 0.5;
+    double skin = 0.7;
     uint32_t K = 4, adapt = 1, use_graph = 0;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
@@ -592,7 +592,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
 {
     const bool tiled = with_list && allow_tiled && want_tiled(s);
     if (with_list) {
-        if (s->W == 0) s->W = 48;
+        if (s->W == 0) s->W = 64;
         s->W = (s->W + GD_UNROLL - 1) & ~(GD_UNROLL - 1);
         const size_t need = (size_t)s->W * s->R * s->Np;   // entries; chunked wave-interleaved layout (k_step)
         if (tiled) { if (s->nbr16.n != need) HIPCHK(s->nbr16.resize(need, false)); }
@@ -645,12 +645,12 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     }
     if (!tover && !over && s->list_tiled && need_t > 0) {
         // size the LDS tile to what the builds actually need (more resident blocks per CU)
-        const unsigned want = std::min(9216u, need_t + need_t / 6 + 64);
+        const unsigned want = std::min(8192u, need_t + need_t / 6 + 64);
         if (want > s->tile_cap || want + want / 4 < s->tile_cap) s->tile_cap = want;
     }
     if (tover) {
         const unsigned cap = need_t + need_t / 8 + 64;
-        if (cap <= 9216) s->tile_cap = cap;    // 144 KB dynamic + static part < 160 KB of LDS per CU
+        if (cap <= 8192) s->tile_cap = cap;    // 128 KB dynamic + static part < 160 KB of LDS per CU
         else s->tiled_ok = false;                // too dense for one tile: generic path
     }
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);

@@ -271,11 +271,18 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     }
     for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
     if (TILED && GD_ABL != 12) {
+        // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
+        // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
+        // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
         const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
             const unsigned len = td->len[k], st = td->start[k], base = td->base[k];
-            for (unsigned q = tid; q < len; q += GD_BLOCK) s_tile[base + q] = rpos[st + q];
+            for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
+                if (q0 + lane < len)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
+                                                     (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
+            }
         }
     }
     if (wid == 0) {
@@ -569,9 +576,9 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
         static bool once = false;
         if (!once) {
             once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
     }
 #define L(PER, TIL, PK) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK>), grid, block, lds, st, p)
@@ -1021,7 +1028,7 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
         static bool once = false;
         if (!once) {
             once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
         hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
         hipLaunchKernelGGL((k_fill<false, true>), gridx, block, (size_t)p.tile_cap * sizeof(float4), st, p);

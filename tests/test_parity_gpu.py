@@ -164,7 +164,7 @@ def test_rollback_is_transparent(hip):
     out = []
     for interval in (1, 60):
         s, dt, kT, flags = build(hip, "genome")
-        s.set_tuning(rebuild_interval=interval, adapt_interval=0)
+        s.set_tuning(rebuild_interval=interval, adapt_interval=0, list_width=128)   # wide list: only skin violations can roll back
         s.begin_phase()
         s.run(60, dt, kT, seed=SEED, flags=flags)
         out.append((s.positions(), s.context().rollbacks))
