@@ -327,13 +327,20 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             // displacement => zero force), so every batch issues its index loads and its
             // neighbour reads together and the loop body has no bounds test.
             const unsigned cntp = (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
+            // software pipeline: the chunk(s) of the next TWO batches are in flight while one is processed
+            uint4 qc = qa, qd = qb;
+            if (GD_UNROLL < cntp) {
+                if (TILED) qc = lst[64];
+                else { qc = lst[(size_t)2 * 64]; qd = lst[(size_t)3 * 64]; }
+            }
             for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
                 unsigned jj[GD_UNROLL];
                 float4 xjv[GD_UNROLL];
                 const uint4 q = qa, q0 = qa, q1 = qb;
-                if (k0 + GD_UNROLL < cntp) {
-                    if (TILED) qa = lst[(size_t)(k0 / 8 + 1) * 64];
-                    else { qa = lst[(size_t)(k0 / 4 + 2) * 64]; qb = lst[(size_t)(k0 / 4 + 3) * 64]; }
+                qa = qc; qb = qd;
+                if (k0 + 2 * GD_UNROLL < cntp) {
+                    if (TILED) qc = lst[(size_t)(k0 / 8 + 2) * 64];
+                    else { qc = lst[(size_t)(k0 / 4 + 4) * 64]; qd = lst[(size_t)(k0 / 4 + 5) * 64]; }
                 }
                 if (TILED) {
                     jj[0] = q.x & 0xffffu; jj[1] = q.x >> 16; jj[2] = q.y & 0xffffu; jj[3] = q.y >> 16;

@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skin", type=float, default=0.0)
     ap.add_argument("--interval", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on the GPU node; gloo for rehearsals")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --dist-backend gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,31 +68,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    dev_index = 0 if a.single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    tdev = "cuda" if a.dist_backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(a.dist_backend)
 
     g = importlib.import_module(PKG)
     wl = importlib.import_module(PKG + ".workloads")
+    farm = importlib.import_module(PKG + ".farm")
     hip = g.load()   # fails loudly if the HIP extension is missing
 
     R, N = a.replicas, a.beads
-    # rank 0 generates the model inputs; RCCL broadcast to the farm (configs[4])
+    # rank 0 generates the model inputs; broadcast to the farm (configs[4]); every rank then owns R
+    # independent replicas -- no collective inside the timed region
+    x0 = None
     if rank == 0:
-        sys_, info = wl.genome_interphase(hip, n_beads=N, n_replicas=R, device=local_rank)
+        sys_, info = wl.genome_interphase(hip, n_beads=N, n_replicas=R, device=dev_index)
         x0 = sys_.positions()
     if world > 1:
-        shape = torch.tensor([R, N, 3], device="cuda")
-        dist.broadcast(shape, 0)
-        xt = torch.from_numpy(x0).cuda() if rank == 0 else torch.empty((R, N, 3), dtype=torch.float64, device="cuda")
-        dist.broadcast(xt, 0)
+        x0 = farm.broadcast_array(x0, (R, N, 3), np.float64, device=tdev)
         if rank != 0:
-            sys_, info = wl.genome_interphase(hip, n_beads=N, n_replicas=R, device=local_rank)
-            sys_.set_positions(xt.cpu().numpy())
+            sys_, info = wl.genome_interphase(hip, n_beads=N, n_replicas=R, device=dev_index)
+            sys_.set_positions(x0)
     if a.skin > 0 or a.interval > 0:
         sys_.set_tuning(skin=a.skin, rebuild_interval=a.interval, adapt_interval=0 if a.interval else 1)
     flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
-    seed = wl.MASTER_SEED + 1000003 * rank    # independent trajectories per rank (and per replica index)
+    seed = farm.replica_seed(wl.MASTER_SEED, rank)    # independent trajectories per rank (and per replica index)
     dt, kT = info["timestep"], info["temperature"]
 
     sys_.begin_phase()
@@ -100,29 +107,24 @@ def main():
     if a.warmup > 0:
         sys_.run(a.warmup, dt, kT, seed=seed, flags=flags)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-    barrier(); torch.cuda.synchronize()
+    farm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     tm = sys_.run(a.steps, dt, kT, seed=seed, flags=flags)      # synchronous: returns after the stream drained
-    torch.cuda.synchronize(); barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    torch.cuda.synchronize(); farm.barrier()
+    el = farm.max_over_ranks(time.perf_counter() - t0, device=tdev)
 
     ctx = sys_.context(0)
     e_mean = float(sys_.energy().mean() / N)
-    stats = torch.tensor([e_mean, ctx.semiaxes[0], float(ctx.rebuild_interval), float(ctx.rollbacks)], device="cuda", dtype=torch.float64)
-    if world > 1:   # gather of summary statistics (a few doubles per rank)
-        gathered = [torch.empty_like(stats) for _ in range(world)] if rank == 0 else None
-        dist.gather(stats, gathered, 0)
-    else:
-        gathered = [stats]
+    gathered = farm.gather_stats([e_mean, ctx.semiaxes[0], float(ctx.rebuild_interval), float(ctx.rollbacks)], device=tdev)
 
     if rank == 0:
+        traffic = None      # HBM bytes per k_step launch from the committed PMC passes, if they are for this workload
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj["workload"] == {"n_beads": N, "replicas_per_gpu": R}:
+                traffic = tj["k_step"]["corrected_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         launches = max(int(tm.step_launches), 1)
         L_launch = tm.list_entries_visited / launches                 # directed entries, all replicas
         bytes_launch = 44.0 * N * R + 28.0 * L_launch                 # 44 N + 28 L per replica-step
@@ -138,9 +140,9 @@ def main():
                        "timestep": dt, "temperature": kT, "list_entries_per_bead": L_launch / (N * R),
                        "rebuild_interval": int(ctx.rebuild_interval), "list_radius": ctx.list_radius,
                        "rollbacks": int(ctx.rollbacks), "equil_steps": a.equil,
-                       "mean_energy_per_bead": [float(s[0]) for s in gathered], "wall_semiaxis": [float(s[1]) for s in gathered]},
+                       "mean_energy_per_bead": [float(v[0]) for v in gathered], "wall_semiaxis": [float(v[1]) for v in gathered]},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kms,
                          "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},
         }
