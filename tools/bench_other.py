@@ -1,0 +1,29 @@
+"""Throughput of the other BASELINE.json configurations (informational lines for DESIGN.md)."""
+import importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+g = importlib.import_module("2022a-genome-dynamics_amd")
+wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
+hip = g.load()
+which = sys.argv[1]
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+if which == "1kb":
+    s, info = wl.chromatin_1kb(hip, n_beads=250000, n_replicas=R); flags = 0
+elif which == "spindle":
+    s, info = wl.spindle(hip, n_beads=300, n_replicas=R); flags = 0
+elif which == "genome62k":
+    s, info = wl.genome_interphase(hip, n_beads=62178, n_replicas=R); flags = 3
+elif which == "abbox":
+    s, info = wl.ab_box(hip, n_replicas=R); flags = 0
+dt, kT = info["timestep"], info["temperature"]
+s.begin_phase()
+s.run(max(steps // 2, 100), dt, kT, seed=5, flags=0)
+s.begin_phase()
+s.run(100, dt, kT, seed=6, flags=flags)
+t0 = time.perf_counter(); tm = s.run(steps, dt, kT, seed=7, flags=flags); el = time.perf_counter() - t0
+c = s.context(); N = info["n_beads"]
+print(json.dumps({"workload": info["workload"], "replicas": R, "bead_steps_per_s": N * R * steps / el, "ms_per_step": el / steps * 1e3,
+                  "step_kernel_ms": tm.step_kernel_ms / tm.step_launches, "rebuild_ms_per_step": tm.rebuild_ms / tm.step_launches,
+                  "L_per_bead": c.list_entries / N, "K": c.rebuild_interval, "rollbacks": c.rollbacks, "E_per_bead": float(s.energy().mean() / N)}))
