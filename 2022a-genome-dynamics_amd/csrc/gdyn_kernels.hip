@@ -285,6 +285,18 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             }
         }
     }
+    // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
+    // and the per-bead loads are in flight (the step index comes from a uniform scalar load)
+    float3 z = make_float3(0.f, 0.f, 0.f);
+    if (MODE == GD_MODE_STEP && GD_ABL != 14 && valid && p.kT > 0.f) {
+        if (p.noise_mode == NOISE_PHILOX) {
+            const long long step_now = p.ctx_in[r].step + (p.ctx_in[r].pending ? 1 : 0);
+            z = philox_normal3(p.seed, oid, step_now + 1, r);
+        } else if (p.noise_mode == NOISE_HOST) {
+            const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
+            z = make_float3(h[0], h[1], h[2]);
+        }
+    }
     if (wid == 0) {
         DevCtx c = p.ctx_in[r];
         if (MODE == GD_MODE_STEP) {
@@ -512,15 +524,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         if (MODE == GD_MODE_STEP) {
             // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
             const float mu_dt = mu * p.dt;
-            float3 z = make_float3(0.f, 0.f, 0.f);
-            if (GD_ABL != 14 && p.kT > 0.f) {
-                const unsigned o = oid;
-                if (p.noise_mode == NOISE_PHILOX) z = philox_normal3(p.seed, o, s_ctx.step + 1, r);
-                else if (p.noise_mode == NOISE_HOST) {
-                    const float *h = p.host_noise + ((size_t)r * p.N + o) * 3;
-                    z = make_float3(h[0], h[1], h[2]);
-                }
-            }
             const float sg = sqrtf(2.0f * p.kT * mu_dt);
             p.pos_out[g] = make_float4(xi.x + mu_dt * F.x + sg * z.x, xi.y + mu_dt * F.y + sg * z.y,
                                        xi.z + mu_dt * F.z + sg * z.z, xi4.w);

@@ -226,3 +226,37 @@ def test_philox_stream_is_counter_based(hip):
     a.run(10, dt, kT, seed=9)
     b.run(4, dt, kT, seed=9); b.run(6, dt, kT, seed=9)
     assert np.abs(a.positions() - b.positions()).max() <= 2e-5
+
+
+def test_dense_cluster_falls_back_to_generic_path(hip, oracle):
+    """Every bead inside one neighbourhood: the LDS tile of a block would be the whole system (> LDS budget).
+    The device flags it, the handle re-plans on the global-gather path, and results still match the oracle."""
+    n = 12000
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(n, 3)) * 0.25                    # ~12k beads within a radius of ~0.6: hundreds of neighbours each
+    out = []
+    for lib in (hip, oracle):
+        s = g.System(lib, n, 1)
+        s.set_bead_params(a=np.ones(n), b=np.zeros(n))
+        s.set_pair_softcore(2.0, 0.30, 2.0, 0.24, mix=True)
+        s.set_positions(x)
+        out.append(s.forces())
+        if lib is hip:
+            s.run(3, 1e-6, 0.0, noise=g.NOISE_ZERO)
+            assert np.isfinite(s.positions()).all()
+    scale = np.abs(out[1]).max()
+    assert np.abs(out[0] - out[1]).max() <= 2e-4 * scale        # ~2000 neighbours per bead: fp32 summation error grows
+
+
+def test_rollback_with_replicas(hip, oracle):
+    """Skin violations roll every replica of the chunk back; all replicas still match the oracle afterwards."""
+    sh, dt, kT, flags = build(hip, "genome", n_replicas=2)
+    so, *_ = build(oracle, "genome", n_replicas=2)
+    sh.set_tuning(rebuild_interval=40, adapt_interval=0, list_width=128)
+    for s in (sh, so):
+        s.begin_phase()
+        s.run(40, dt, kT, seed=SEED, flags=flags)
+    assert sh.context().rollbacks >= 1
+    assert np.abs(sh.positions() - so.positions()).max() <= 1e-4
+    for r in range(2):
+        assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), atol=1e-8)
