@@ -251,7 +251,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 
     // every independent per-bead load is issued up front, ahead of the tile staging and the barrier,
     // so their latencies overlap (the kernel is latency-bound, not ALU-bound)
-    const unsigned slot = blk * GD_BLOCK + tid;
+    // thread -> bead assignment: the build sorted each block's beads by pair-list length, so the 64 lanes
+    // of a wave run (almost) the same number of list batches instead of waiting for their longest list
+    const unsigned slot = blk * GD_BLOCK + p.perm[rbase + blk * GD_BLOCK + tid];
     const bool valid = slot < p.N;
     const size_t g = rbase + slot;
     const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
@@ -1009,6 +1011,19 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             cnt = found;
         }
         p.meta[g] = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
+    }
+    // block-local counting sort of the beads by list batches (longest first) -> perm for k_step
+    {
+        __shared__ unsigned s_hist[32], s_off[32];
+        if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned nb = slot < p.N ? min((min(cnt, p.W) + GD_UNROLL - 1u) / GD_UNROLL, 30u) : 0u;
+        const unsigned bin = slot < p.N ? 30u - nb : 31u;                 // pad slots last
+        const unsigned rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned run = 0; for (int b = 0; b < 32; b++) { s_off[b] = run; run += s_hist[b]; } }
+        __syncthreads();
+        p.perm[rbase + blk * GD_BLOCK + s_off[bin] + rank] = (unsigned short)threadIdx.x;
     }
     unsigned long long c64 = min(cnt, p.W);
     for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o, 64);
