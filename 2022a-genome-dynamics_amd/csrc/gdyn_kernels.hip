@@ -65,12 +65,13 @@ __device__ __forceinline__ float pack_ab(float2 ab)
 
 // softcore<2,3> + softcore<8,3> (the pair force of all four reference models), branch-free:
 // the clamp makes each term vanish beyond its own diameter.  ca = 6 eps_a / sa^2, cb = 24 eps_b / sb^2.
-__device__ __forceinline__ float softcore_2383(float r2, float inv_sa2, float inv_sb2, float ca, float cb, float wa, float wb)
+// waca = wa*ca and wbcb = wb*cb come in pre-multiplied (one fma each from the neighbour's a/b).
+__device__ __forceinline__ float softcore_2383(float r2, float inv_sa2, float inv_sb2, float waca, float wbcb)
 {
-    const float ga = fmaxf(1.0f - r2 * inv_sa2, 0.0f);
+    const float ga = fmaxf(fmaf(-r2, inv_sa2, 1.0f), 0.0f);
     const float u2 = r2 * inv_sb2, u4 = u2 * u2;
-    const float gb = fmaxf(1.0f - u4 * u4, 0.0f);
-    return wa * ca * ga * ga + wb * cb * gb * gb * u4 * u2;
+    const float gb = fmaxf(fmaf(-u4, u4, 1.0f), 0.0f);
+    return fmaf(wbcb * (gb * gb), u4 * u2, waca * (ga * ga));
 }
 __device__ __forceinline__ float softcore_2383_energy(float r2, float inv_sa2, float inv_sb2, float ea, float eb, float wa, float wb)
 {
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             const float inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f, inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
             const float cut = p.pair.cutoff * sc, cut2 = cut * cut;
             const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb = 24.0f * p.pair.eps_b * inv_sb2;
+            const float hca = 0.5f * ca, hcb = 0.5f * cb, Ai = hca * abi.x, Bi = hcb * abi.y;
             const unsigned cnt = meta >> 16;
             // Pair lists are stored in chunks of 16 bytes per bead, wave-interleaved:
             // chunk c of bead g is uint4 #((g/64)*NC + c)*64 + g%64  (one coalesced 1 KiB read per wave).
@@ -373,12 +375,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                     const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
                     float wa = 1.0f, wb = 1.0f;
                     if (PK != 0) {
+                        float waca = ca, wbcb = cb;
                         if (PK == 1) {
                             const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
-                            wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y);
+                            waca = fmaf(abj.x, hca, Ai); wbcb = fmaf(abj.y, hcb, Bi);      // (a_i+a_j)/2 * ca, (b_i+b_j)/2 * cb
+                            if (MODE == GD_MODE_ENERGY) { wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y); }
                         }
-                        const float f = softcore_2383(r2, inv_sa2, inv_sb2, ca, cb, wa, wb);
-                        F.x += f * d.x; F.y += f * d.y; F.z += f * d.z;
+                        const float f = softcore_2383(r2, inv_sa2, inv_sb2, waca, wbcb);
+                        F.x = fmaf(f, d.x, F.x); F.y = fmaf(f, d.y, F.y); F.z = fmaf(f, d.z, F.z);
                         if (MODE == GD_MODE_ENERGY && k0 + u < cnt)
                             E += 0.5f * softcore_2383_energy(r2, inv_sa2, inv_sb2, p.pair.eps_a, p.pair.eps_b, wa, wb);
                     } else if (r2 < cut2) {
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             }
             return false;
         };
-        const unsigned deg = p.bdeg_o[o];
+        const unsigned deg = (GD_ABL == 3 || GD_ABL == 4) ? 0u : p.bdeg_o[o];
         unsigned *__restrict__ adjw = (unsigned *)((uint4 *)p.badj + (size_t)(g >> 6) * (p.WB / 4) * 64 + (g & 63));
         for (unsigned k = 0; k < deg; k++) {
             const unsigned ent = p.badj_o[(size_t)k * p.N + o];
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 for (int k = 0; k < GD_TILE_RANGES; k++) {
                     const int zz = cz + k / 3 - 1, yy = cy + k % 3 - 1;
                     rb[k] = 0; re[k] = 0;
-                    if (zz < 0 || zz >= gp.nc[2] || yy < 0 || yy >= gp.nc[1] || s_td.kstart[k] == 0xffffffffu) continue;
+                    if (GD_ABL == 5 || zz < 0 || zz >= gp.nc[2] || yy < 0 || yy >= gp.nc[1] || s_td.kstart[k] == 0xffffffffu) continue;
                     const unsigned row = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0]);
                     rb[k] = cs[row + x_lo]; re[k] = cs[row + x_hi + 1];
                 }
