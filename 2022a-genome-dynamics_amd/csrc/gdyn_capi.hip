@@ -473,8 +473,8 @@ static int finalize_topology(gd_system *s)
     std::vector<BondType> bt(std::max<size_t>(types.size(), 1));
     for (size_t i = 0; i < types.size(); i++) {
         const gd_bond_params &p = types[i];
-        bt[i] = BondType{p.kind, p.mix, p.scale_by_bond_scale, p.p, p.q, p.minimum_image, terms[i],
-                         (float)p.k_a, (float)p.k_b, (float)p.l_a, (float)p.l_b};
+        bt[i] = BondType{(float)p.k_a, (float)p.k_b, (float)p.l_a, (float)p.l_b, p.kind,
+                         (p.mix ? 1 : 0) | (p.scale_by_bond_scale ? 2 : 0) | (p.minimum_image ? 4 : 0), p.p | (p.q << 8), terms[i]};
     }
     // bending: energy of the triplet starting at each bead
     std::vector<double> tE(N, 0.0);

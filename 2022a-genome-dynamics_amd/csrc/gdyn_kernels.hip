@@ -145,9 +145,9 @@ __device__ __forceinline__ void bond_pot(int kind, float K, float l, int P, int 
     } else if (kind == POT_SOFTCORE) {
         softcore(K, 1.0f / (l * l), P, Q, r2, e, fr);
     } else {
-        const float d = sqrtf(r2);
-        const float x = d - l;
-        if (kind == POT_SPRING || x > 0.0f) { e = 0.5f * K * x * x; fr = d > 0.0f ? -K * x / d : 0.0f; }
+        const float inv_d = r2 > 0.0f ? rsqrtf(r2) : 0.0f;     // d = r2 * inv_d, no divide
+        const float x = r2 * inv_d - l;
+        if (kind == POT_SPRING || x > 0.0f) { e = 0.5f * K * x * x; fr = -K * x * inv_d; }
     }
 }
 
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
         if (GD_ABL != 13 && p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
             const unsigned deg = meta & 0xffu;
+            const float inv_bs2 = 1.0f / (s_ctx.bond_scale * s_ctx.bond_scale);
             uint4 aq = adj0;
             for (unsigned k = 0; k < deg; k++) {
                 if (k && (k & 3u) == 0) aq = adj[(size_t)(k >> 2) * 64];
@@ -422,17 +423,17 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                 float4 xj;
                 if (TILED && (ent & GD_ADJ_LOCAL)) xj = s_tile[j]; else xj = rpos[j];
                 float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
-                if (PERIODIC && bt.minimg) d = min_image(d, p.box, p.inv_box);
+                if (PERIODIC && (bt.flags & 4)) d = min_image(d, p.box, p.inv_box);
                 const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
                 float K = bt.ka, l = bt.la;
-                if (bt.mix) {
+                if (bt.flags & 1) {
                     const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
                     const float a = 0.5f * (abi.x + abj.x), b = 0.5f * (abi.y + abj.y);
                     K = a * bt.ka + b * bt.kb; l = a * bt.la + b * bt.lb;
                 }
-                if (bt.scaled) { const float s = s_ctx.bond_scale; K = K * (1.0f / (s * s)); l = l * s; }
+                if (bt.flags & 2) { K = K * inv_bs2; l = l * s_ctx.bond_scale; }
                 float e, fr;
-                bond_pot(bt.kind, K, l, bt.p, bt.q, r2, e, fr);
+                bond_pot(bt.kind, K, l, bt.pq & 0xff, bt.pq >> 8, r2, e, fr);
                 F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
                 if (MODE == GD_MODE_ENERGY) E += 0.5f * e;
             }

@@ -75,9 +75,12 @@ struct WallP {
     double spring[3], mobility;
 };
 
-struct BondType {
-    int kind, mix, scaled, p, q, minimg, term;
+struct BondType {               // 32 bytes: two 16-byte LDS reads per bond
     float ka, kb, la, lb;
+    int kind;
+    int flags;                  // mix | scaled << 1 | minimg << 2
+    int pq;                     // p | q << 8 (GD_POT_SOFTCORE)
+    int term;
 };
 
 struct PointSrc {
