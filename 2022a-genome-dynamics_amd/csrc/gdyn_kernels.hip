@@ -958,17 +958,20 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     for (unsigned j0 = lb; j0 < le; j0 += 32) {
                         const unsigned n = min(32u, le - j0);
                         unsigned m = 0;
+                        // no per-candidate bookkeeping: reads may run up to 3 slots past the window (slack is
+                        // allocated behind the tile); the window end and the bead itself are masked once
                         for (unsigned u0 = 0; u0 < n; u0 += 4) {
-                            float4 xj[4];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) xj[u] = s_tile[min(j0 + u0 + u, le - 1)];
+                            const float4 *cj = s_tile + j0 + u0;
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
-                                const float dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z;
-                                const bool acc = (u0 + u < n) & (dx * dx + dy * dy + dz * dz < rv2) & (j0 + u0 + u != self_l);
-                                m |= (acc ? 1u : 0u) << (u0 + u);
+                                const float4 xj = cj[u];
+                                const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                                m |= (dx * dx + dy * dy + dz * dz < rv2 ? 1u : 0u) << (u0 + u);
                             }
                         }
+                        if (n < 32u) m &= (1u << n) - 1u;
+                        const unsigned sd = self_l - j0;
+                        if (sd < 32u) m &= ~(1u << sd);
                         while (m) {
                             const unsigned bit = __ffs(m) - 1;
                             m &= m - 1;
@@ -1061,7 +1064,7 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
         hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
-        hipLaunchKernelGGL((k_fill<false, true>), gridx, block, (size_t)p.tile_cap * sizeof(float4), st, p);
+        hipLaunchKernelGGL((k_fill<false, true>), gridx, block, (size_t)(p.tile_cap + 4) * sizeof(float4), st, p);   // +4: read slack
     } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false>), gridx, block, 0, st, p);
     else hipLaunchKernelGGL((k_fill<false, false>), gridx, block, 0, st, p);
 }
