@@ -23,7 +23,7 @@ def gdyn():
 @pytest.fixture(scope="session")
 def oracle(gdyn):
     """The CPU fp64 oracle bound through the same ctypes ABI (test infrastructure)."""
-    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    path = os.environ.get("GDYN_ORACLE_LIB", os.path.join(ROOT, "oracle", "liboracle.so"))   # e.g. a sanitizer build
     if not os.path.exists(path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     lib = gdyn.Lib(path)

@@ -260,3 +260,30 @@ def test_rollback_with_replicas(hip, oracle):
     assert np.abs(sh.positions() - so.positions()).max() <= 1e-4
     for r in range(2):
         assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), atol=1e-8)
+
+
+@pytest.mark.parametrize("powers", [(4, 2, 12, 1), (6, 4, 2, 3), (2, 1, 8, 4)])
+def test_runtime_softcore_powers_and_unpackable_factors(hip, oracle, powers):
+    """The generic code paths: runtime (P,Q) soft cores, a/b factors that are not fp16-exact (so they are gathered
+    from the float2 array and the tiled path is off), non-uniform mobilities, negative (attractive) energy."""
+    n = 1200
+    rng = np.random.default_rng(11)
+    x = rng.random((n, 3)) * 2.2
+    a, b = rng.random(n) * 0.9 + 0.05, rng.random(n) * 1.3
+    mob = 0.5 + rng.random(n)
+    pa, qa, pb, qb = powers
+    out = []
+    for lib in (hip, oracle):
+        s = g.System(lib, n, 2)
+        s.set_bead_params(a=a, b=b, mobility=mob)
+        s.set_pair_softcore(2.0, 0.30, -0.7, 0.36, pa, qa, pb, qb, mix=True)
+        s.add_bond_range(g.System.bond_params(g.POT_SPRING, 40.0, 0.25, k_b=10.0, l_b=0.2, mix=True), 0, n)
+        xs = np.stack([x, x + 0.01 * rng.normal(size=x.shape)]) if lib is hip else xs
+        s.set_positions(xs)
+        f, e = s.forces(), s.energy()
+        s.run(5, 2e-5, 0.3, seed=SEED)
+        out.append((f, e, s.positions()))
+    scale = np.abs(out[1][0]).max()
+    assert np.abs(out[0][0] - out[1][0]).max() <= FORCE_RTOL * scale
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-5)
+    assert np.abs(out[0][2] - out[1][2]).max() <= POS_ATOL_20STEP

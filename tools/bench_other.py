@@ -9,6 +9,7 @@ hip = g.load()
 which = sys.argv[1]
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+skin = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 if which == "1kb":
     s, info = wl.chromatin_1kb(hip, n_beads=250000, n_replicas=R); flags = 0
 elif which == "spindle":
@@ -18,6 +19,7 @@ elif which == "genome62k":
 elif which == "abbox":
     s, info = wl.ab_box(hip, n_replicas=R); flags = 0
 dt, kT = info["timestep"], info["temperature"]
+if skin > 0: s.set_tuning(skin=skin)
 s.begin_phase()
 s.run(max(steps // 2, 100), dt, kT, seed=5, flags=0)
 s.begin_phase()
