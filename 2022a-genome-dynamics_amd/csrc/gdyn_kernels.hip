@@ -334,6 +334,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             const float cut = p.pair.cutoff * sc, cut2 = cut * cut;
             const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb = 24.0f * p.pair.eps_b * inv_sb2;
             const float hca = 0.5f * ca, hcb = 0.5f * cb, Ai = hca * abi.x, Bi = hcb * abi.y;
+            if (MODE == GD_MODE_STEP) {
+                // Verlet-skin check: the list is complete for this force evaluation iff every
+                // bead moved less than (rv - cutoff)/2 since the build.
+                const float dx = xi.x - x0.x, dy = xi.y - x0.y, dz = xi.z - x0.z;
+                disp2 = dx * dx + dy * dy + dz * dz;
+                const float lim = 0.5f * (p.rv - cut);
+                if (!(lim > 0.f) || disp2 > lim * lim) p.flags[r * GD_NFLAGS + GD_FLAG_VIOLATION] = 1u;
+            }
             const unsigned cnt = meta >> 16;
             // Pair lists are stored in chunks of 16 bytes per bead, wave-interleaved:
             // chunk c of bead g is uint4 #((g/64)*NC + c)*64 + g%64  (one coalesced 1 KiB read per wave).
@@ -343,20 +351,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             // displacement => zero force), so every batch issues its index loads and its
             // neighbour reads together and the loop body has no bounds test.
             const unsigned cntp = (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
-            // software pipeline: the chunk(s) of the next TWO batches are in flight while one is processed
-            uint4 qc = qa, qd = qb;
-            if (GD_UNROLL < cntp) {
-                if (TILED) qc = lst[64];
-                else { qc = lst[(size_t)2 * 64]; qd = lst[(size_t)3 * 64]; }
-            }
+            // software pipeline: the chunk(s) of the next batch are in flight while one is processed
+            // (a second batch of look-ahead bought nothing and costs the registers of one occupancy step)
             for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
                 unsigned jj[GD_UNROLL];
                 float4 xjv[GD_UNROLL];
                 const uint4 q = qa, q0 = qa, q1 = qb;
-                qa = qc; qb = qd;
-                if (k0 + 2 * GD_UNROLL < cntp) {
-                    if (TILED) qc = lst[(size_t)(k0 / 8 + 2) * 64];
-                    else { qc = lst[(size_t)(k0 / 4 + 4) * 64]; qd = lst[(size_t)(k0 / 4 + 5) * 64]; }
+                if (k0 + GD_UNROLL < cntp) {
+                    if (TILED) qa = lst[(size_t)(k0 / 8 + 1) * 64];
+                    else { qa = lst[(size_t)(k0 / 4 + 2) * 64]; qb = lst[(size_t)(k0 / 4 + 3) * 64]; }
                 }
                 if (TILED) {
                     jj[0] = q.x & 0xffffu; jj[1] = q.x >> 16; jj[2] = q.y & 0xffffu; jj[3] = q.y >> 16;
@@ -398,14 +401,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                         if (MODE == GD_MODE_ENERGY && k0 + u < cnt) E += 0.5f * (wa * ea + wb * eb);
                     }
                 }
-            }
-            if (MODE == GD_MODE_STEP) {
-                // Verlet-skin check: the list is complete for this force evaluation iff every
-                // bead moved less than (rv - cutoff)/2 since the build.
-                const float dx = xi.x - x0.x, dy = xi.y - x0.y, dz = xi.z - x0.z;
-                disp2 = dx * dx + dy * dy + dz * dz;
-                const float lim = 0.5f * (p.rv - cut);
-                if (!(lim > 0.f) || disp2 > lim * lim) p.flags[r * GD_NFLAGS + GD_FLAG_VIOLATION] = 1u;
             }
         }
 

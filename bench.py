@@ -113,6 +113,18 @@ def main():
     torch.cuda.synchronize(); farm.barrier()
     el = farm.max_over_ranks(time.perf_counter() - t0, device=tdev)
 
+    # second figure: the same stepping with the reference's observation cadence -- mean energy every
+    # interphase_logging_interval = 100 steps, a quantised snapshot every interphase_sampling_interval = 1000 steps
+    # (config_entries.inc:81-82); 1000 extra steps, not part of `value`
+    farm.barrier()
+    t1 = time.perf_counter()
+    for k in range(10):
+        sys_.run(100, dt, kT, seed=seed, flags=flags)
+        e_obs = sys_.energy()
+    snap = sys_.positions_f32(quantize=True)
+    obs_rate = N * R * 1000 / (time.perf_counter() - t1)
+    del snap, e_obs
+
     ctx = sys_.context(0)
     e_mean = float(sys_.energy().mean() / N)
     gathered = farm.gather_stats([e_mean, ctx.semiaxes[0], float(ctx.rebuild_interval), float(ctx.rollbacks)], device=tdev)
@@ -140,6 +152,7 @@ def main():
                        "timestep": dt, "temperature": kT, "list_entries_per_bead": L_launch / (N * R),
                        "rebuild_interval": int(ctx.rebuild_interval), "list_radius": ctx.list_radius,
                        "rollbacks": int(ctx.rollbacks), "equil_steps": a.equil,
+                       "bead_steps_per_s_with_reference_cadence_rank0": obs_rate,
                        "mean_energy_per_bead": [float(v[0]) for v in gathered], "wall_semiaxis": [float(v[1]) for v in gathered]},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
