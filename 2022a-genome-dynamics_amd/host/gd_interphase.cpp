@@ -26,11 +26,12 @@
 
 #include "../../include/gdyn.h"
 #include "gd_config.hpp"
+#include "gd_genome_model.hpp"
 #include "gd_store.hpp"
 
 namespace {
 
-void chk(int rc) { if (rc != GD_OK) throw std::runtime_error(gd_last_error()); }
+using gd::chk;
 
 // Time-integrated contact map (simulation_interphase/contact_map.cc:31-91): unique pairs (i<j) within the
 // contact distance are counted at every update; accumulate() lists (i, j, count) in row-major order.
@@ -71,8 +72,6 @@ public:
         set_default(_config.a_core_bond_length, _config.chromatin_bond_length);
         set_default(_config.b_core_bond_spring, _config.chromatin_bond_spring);
         set_default(_config.b_core_bond_length, _config.chromatin_bond_length);
-        if (_config.nucleolus_droplet_energy != 0)
-            throw std::runtime_error("nucleolus_droplet_energy != 0 (softwell droplet force) is not supported yet");
         setup(device);
     }
     ~simulation_driver() { gd_destroy(_sys); }
@@ -82,58 +81,12 @@ public:
 private:
     void setup(int device)
     {
-        auto const particles = _store.load_particle_data();
         _chromosomes = _store.load_chromosomes();
-        auto const nucleoli = _store.load_nucleolus_ranges();
-        _n = particles.size();
-        gd_desc desc{};
-        desc.n_beads = (uint32_t)_n; desc.n_replicas = 1; desc.device = device; desc.box_kind = GD_BOX_OPEN;
-        chk(gd_create(&desc, &_sys));
-        // particles (simulation_driver_particles.cc:8-36)
-        std::vector<double> a(_n), b(_n), mobility(_n, 1.0);
-        for (std::size_t i = 0; i < _n; i++) { a[i] = particles[i].a; b[i] = particles[i].b; }
-        for (auto const &c : _chromosomes) for (std::size_t i = c.start; i < c.end; i++) mobility[i] = _config.chromatin_mobility;
-        for (auto const &r : nucleoli) for (std::size_t i = r.begin; i < r.end; i++) mobility[i] = _config.nucleolus_mobility;
-        chk(gd_set_bead_params(_sys, a.data(), b.data(), mobility.data(), nullptr));
-        // repulsion (simulation_driver_forcefield.cc:19-51)
-        gd_pair_softcore pair{};
-        pair.eps_a = _config.a_core_repulsion; pair.sigma_a = _config.a_core_diameter; pair.p_a = 2; pair.q_a = 3;
-        pair.eps_b = _config.b_core_repulsion; pair.sigma_b = _config.b_core_diameter; pair.p_b = 8; pair.q_b = 3;
-        pair.mix = 1; pair.scale_by_bead_scale = 1;
-        chk(gd_set_pair_softcore(_sys, &pair));
-        // connectivity (:54-89) and mean-field (i,i+2) loops (:92-128)
-        gd_bond_params chain{};
-        chain.kind = GD_POT_SEMISPRING; chain.mix = 1; chain.scale_by_bond_scale = 1;
-        chain.k_a = _config.a_core_bond_spring; chain.k_b = _config.b_core_bond_spring;
-        chain.l_a = _config.a_core_bond_length; chain.l_b = _config.b_core_bond_length;
-        gd_bond_params loop{};
-        loop.kind = GD_POT_HARMONIC; loop.mix = 1; loop.scale_by_bond_scale = 1;
-        loop.k_a = _config.a_core_2nd_bond_spring; loop.k_b = _config.b_core_2nd_bond_spring;
-        for (auto const &c : _chromosomes) {
-            chk(gd_add_bond_range(_sys, &chain, (uint32_t)c.start, (uint32_t)c.end, 1));
-            chk(gd_add_bond_range(_sys, &loop, (uint32_t)c.start, (uint32_t)c.end, 2));
-        }
-        // nucleolar side chains (:131-151)
-        gd_bond_params nuc{};
-        nuc.kind = GD_POT_SEMISPRING; nuc.scale_by_bond_scale = 1;
-        nuc.k_a = _config.nucleolus_bond_spring; nuc.l_a = _config.nucleolus_bond_length;
-        std::vector<uint32_t> pairs;
-        for (auto const &bond : _store.load_nucleolus_bonds()) { pairs.push_back((uint32_t)bond.nor_index); pairs.push_back((uint32_t)bond.nuc_index); }
-        if (!pairs.empty()) chk(gd_add_bond_pairs(_sys, &nuc, pairs.data(), (uint32_t)(pairs.size() / 2)));
-        // membrane (:182-235)
-        gd_wall wall{};
-        wall.eps_a = _config.a_core_repulsion; wall.sigma_a = _config.a_core_diameter; wall.p_a = 2; wall.q_a = 3;
-        wall.eps_b = _config.b_core_repulsion; wall.sigma_b = _config.b_core_diameter; wall.p_b = 8; wall.q_b = 3;
-        wall.wall_a_factor = _config.wall_a_factor; wall.wall_b_factor = _config.wall_b_factor; wall.scale_by_bead_scale = 1;
-        wall.packing_spring = _config.wall_packing_spring; wall.mobility = _config.wall_mobility;
-        double const spring[3] = {_config.wall_semiaxes_spring.x, _config.wall_semiaxes_spring.y, _config.wall_semiaxes_spring.z};
-        double const semi[3] = {_config.wall_init_semiaxes.x, _config.wall_init_semiaxes.y, _config.wall_init_semiaxes.z};
-        std::copy(spring, spring + 3, wall.semiaxes_spring); std::copy(semi, semi + 3, wall.init_semiaxes);
-        chk(gd_set_ellipsoid_wall(_sys, &wall));
-        chk(gd_set_scaling(_sys, _config.bead_scale_init, _config.bead_scale_tau, _config.bond_scale_init, _config.bond_scale_tau));
+        _sys = gd::build_genome_system(_store, _config, device, /*loop_bonds=*/true, /*mixed_chain_bonds=*/true, _n);
         // setup_context (simulation_driver.cc:43-51)
         _context = gd::context{};
-        std::copy(semi, semi + 3, _context.wall_semiaxes);
+        _context.wall_semiaxes[0] = _config.wall_init_semiaxes.x; _context.wall_semiaxes[1] = _config.wall_init_semiaxes.y;
+        _context.wall_semiaxes[2] = _config.wall_init_semiaxes.z;
         _context.bead_scale = _config.bead_scale_init; _context.bond_scale = _config.bond_scale_init;
         _buffer.resize(3 * _n);
     }

@@ -1,5 +1,6 @@
 """The C++ host side above the C-ABI: trajectory store in the reference's HDF5 layout and
-the `gd_interphase` driver (relaxation + interphase phases, logging cadence, contact map).  The driver is
+the drivers `gd_interphase` (relaxation + interphase phases, logging cadence, contact map), `gd_spindle`
+(coarse-grained spindle + packing phases) and `gd_fine_sampling` (deterministic continuation).  The driver is
 backend-agnostic C++; the CPU test links it against the oracle library, the GPU test against libgdyn, and both
 compare the files it writes with the same sequence of ABI calls issued from Python."""
 import ctypes as C
@@ -21,10 +22,15 @@ pytestmark = pytest.mark.skipif(not os.path.exists("/opt/conda/include/hdf5.h"),
 N, RELAX, INTER = 600, 40, 60
 
 
-def _make(driver, libdir, lib):
-    """Builds the tools; `driver` may be a path outside the product tree (the oracle-linked test binary)."""
+def _make(name, outdir, libdir, lib):
+    """Builds the tools; `outdir` may lie outside the product tree (the oracle-linked test binaries)."""
     subprocess.check_call(["make", "-s", "-C", HOST, "h5lib/libhdf5.so", "gd_h5tool"])
-    subprocess.check_call(["make", "-s", "-C", HOST, str(driver), f"DRIVER={driver}", f"GDYN_LIBDIR={libdir}", f"GDYN_LIB={lib}"])
+    subprocess.check_call(["make", "-s", "-C", HOST, f"{outdir}/{name}", f"OUTDIR={outdir}", f"GDYN_LIBDIR={libdir}", f"GDYN_LIB={lib}"])
+    return os.path.join(HOST, outdir, name)
+
+
+def _make_oracle(name, tmp):
+    return _make(name, str(tmp), os.path.join(ROOT, "oracle"), "oracle")
 
 
 def _env(*libdirs):
@@ -179,8 +185,7 @@ def _check_run(tmp, lib, oracle, driver, atol, env=None):
 
 
 def test_store_layout_and_driver_on_oracle(tmp_path, oracle):
-    drv = tmp_path / "gd_interphase_oracle"       # test-only binary: the same driver source linked against the oracle
-    _make(drv, os.path.join(ROOT, "oracle"), "oracle")
+    drv = _make_oracle("gd_interphase", tmp_path)     # test-only binary: the same driver source linked against the oracle
     path = _check_run(tmp_path, oracle, oracle, drv, atol=0, env=_env(os.path.join(ROOT, "oracle")))
     if os.path.exists(H5DUMP):      # the on-disk layout the reference's readers rely on
         hdr = subprocess.check_output([H5DUMP, "-H", "-p", str(path)], text=True)
@@ -197,8 +202,7 @@ def test_store_layout_and_driver_on_oracle(tmp_path, oracle):
 
 
 def test_missing_config_key_is_an_error(tmp_path, oracle):
-    drv = tmp_path / "gd_interphase_oracle"
-    _make(drv, os.path.join(ROOT, "oracle"), "oracle")
+    drv = _make_oracle("gd_interphase", tmp_path)
     cfg, *_ = _inputs(tmp_path)
     del cfg["wall_mobility"]
     (tmp_path / "config.json").write_text(json.dumps(cfg))
@@ -210,5 +214,233 @@ def test_missing_config_key_is_an_error(tmp_path, oracle):
 
 @pytest.mark.gpu
 def test_driver_on_gpu(tmp_path, hip, oracle):
-    _make("gd_interphase", "../csrc", "gdyn")
-    _check_run(tmp_path, hip, oracle, os.path.join(HOST, "gd_interphase"), atol=2e-4)
+    _check_run(tmp_path, hip, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------- gd_spindle
+
+class _Mt64:
+    """std::mt19937_64 draws through the oracle's generator, plus libstdc++'s std::normal_distribution<double>
+    (Marsaglia polar method on generate_canonical<double, 53>: one 64-bit draw per uniform) -- what
+    simulation_spindle/simulation_driver.cc:189-199 consumes from `_random`."""
+
+    def __init__(self, oracle, seed):
+        self.oracle, self.seed, self.n = oracle, seed, 0
+
+    def draw(self):
+        self.n += 1
+        return _mt64(self.oracle, self.seed, self.n)
+
+    def canonical(self):
+        r = float(self.draw()) / 18446744073709551616.0
+        return r if r < 1.0 else float(np.nextafter(1.0, 0.0))
+
+    def normals(self, count):
+        """`count` values from a freshly constructed distribution object."""
+        import math
+        out, saved = [], None
+        while len(out) < count:
+            if saved is not None:
+                out.append(saved)
+                saved = None
+                continue
+            while True:
+                x = 2.0 * self.canonical() - 1.0
+                y = 2.0 * self.canonical() - 1.0
+                r2 = x * x + y * y
+                if not (r2 > 1.0 or r2 == 0.0):
+                    break
+            mult = math.sqrt(-2 * math.log(r2) / r2)
+            saved = x * mult
+            out.append(y * mult)
+        return out
+
+
+SP_COARSE, SP_STEPS, SP_PACK = 2, 40, 30
+
+
+def _spindle_inputs(tmp):
+    lens = wl.chain_lengths(N)
+    cfg = dict(wl.DEFAULT_CONFIG)
+    cfg.update(init_coarse_graining=SP_COARSE, init_bend_energy=1.0, init_packing_spring=0.5, init_packing_radius=1.0,
+               init_spindle_steps=SP_STEPS, init_packing_steps=SP_PACK, init_sampling_interval=20, init_logging_interval=10,
+               init_start_stddev=0.5, spindle_seed=2024)
+    (tmp / "config.json").write_text(json.dumps(cfg))
+    st, rows, fine = 0, [], []
+    for k, n in enumerate(lens):
+        cen = st + int(n) // 2
+        rows.append(f"chr{k + 1} {st} {st + n} {cen} {cen + 1}")
+        fine.append((st, st + int(n), cen, cen + 1))
+        st += int(n)
+    (tmp / "chroms.tsv").write_text("\n".join(rows) + "\n")
+    np.zeros((N, 2), dtype="<f8").tofile(tmp / "ab.f64")
+    np.zeros((N, 3), dtype="<f8").tofile(tmp / "pos.f64")
+    subprocess.check_call([os.path.join(HOST, "gd_h5tool"), "make-input", str(tmp / "traj.h5"), str(tmp / "config.json"),
+                           str(tmp / "chroms.tsv"), str(tmp / "ab.f64"), str(tmp / "pos.f64")])
+    chains, start = [], 0
+    for (b0, b1, c0, c1) in fine:                                  # simulation_spindle/simulation_driver.cc:46-68
+        size, cen = b1 - b0, (c0 + c1) // 2
+        csize, ccen = (size + SP_COARSE - 1) // SP_COARSE, (cen - b0) // SP_COARSE
+        chains.append((start, start + csize, start + ccen))
+        start += csize
+    return cfg, chains, start
+
+
+def _python_spindle(lib, oracle, cfg, chains, n):
+    rnd = _Mt64(oracle, cfg["spindle_seed"])
+    x = np.zeros((n, 3))
+    for (c0, c1, _) in chains:
+        z = rnd.normals(6)
+        centroid = np.array([cfg["init_start_point"][k] + cfg["init_start_stddev"] * z[k] for k in range(3)])
+        d = np.array(z[3:])
+        norm = float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
+        step = cfg["init_bond_length"] * (d * (1 / norm))
+        pos = centroid - step * float(c1 - c0) / 2
+        for i in range(c0, c1):
+            x[i] = pos
+            pos = pos + step
+    s = g.System(lib, n, 1)
+    s.set_bead_params(mobility=np.full(n, cfg["init_mobility"]))
+    s.set_pair_softcore(cfg["init_bead_repulsion"], cfg["init_bead_diameter"], 0.0, 0.0, 2, 3, 2, 3, mix=False)
+    bond = g.System.bond_params(g.POT_SEMISPRING, k_a=cfg["init_bond_spring"], l_a=cfg["init_bond_length"])
+    for (c0, c1, _) in chains:
+        s.add_bond_range(bond, c0, c1, 1)
+        s.add_bending_range(c0, c1, cfg["init_bend_energy"])
+    s.set_positions(x)
+    out, energies = {}, {}
+    for phase, steps in (("spindle", SP_STEPS), ("packing", SP_PACK)):
+        if phase == "spindle":
+            s.add_point_source(g.POT_HARMONIC, cfg["init_spindle_spring"], 0.0, cfg["init_spindle_point"],
+                               targets=[c + d for (_, _, c) in chains for d in (-1, 0, 1)])
+        else:
+            s.add_point_source(g.POT_SEMISPRING, cfg["init_packing_spring"], cfg["init_packing_radius"], cfg["init_spindle_point"])
+        s.begin_phase()
+        seed = rnd.draw()
+        step = 0
+        out[(phase, 0)] = s.positions_f32(quantize=True)[0].astype(np.float64)
+        energies[(phase, 0)] = float(s.energy()[0]) / n
+        while step < steps:
+            s.run(10, cfg["init_timestep"], cfg["init_temperature"], seed=seed)
+            step += 10
+            energies[(phase, step)] = float(s.energy()[0]) / n
+            if step % 20 == 0:
+                out[(phase, step)] = s.positions_f32(quantize=True)[0].astype(np.float64)
+    s.close()
+    return out, energies
+
+
+def _check_spindle(tmp, lib, oracle, driver, atol, env=None):
+    cfg, chains, n = _spindle_inputs(tmp)
+    log = subprocess.run([str(driver), str(tmp / "traj.h5")], capture_output=True, text=True, env=env)
+    assert log.returncode == 0, log.stderr
+    lines = [ln for ln in log.stderr.splitlines() if ln.startswith("[")]
+    assert [ln.split("]")[0][1:] for ln in lines] == ["spindle"] * (SP_STEPS // 10 + 1) + ["packing"] * (SP_PACK // 10 + 1)
+    assert _tool("steps", tmp / "traj.h5", "spindle").split() == ["0", "20", "40"]
+    assert _tool("steps", tmp / "traj.h5", "packing").split() == ["0", "20"]
+    ref, energies = _python_spindle(lib, oracle, cfg, chains, n)
+    for (phase, step), pos in ref.items():
+        got = _positions(tmp, phase, step)
+        assert got.shape == (n, 3)
+        assert np.abs(got - pos).max() <= atol, (phase, step)
+    # "[phase] date time \t step \t E: energy-per-bead" (simulation_driver.cc:275-292)
+    for ln in lines:
+        phase = ln.split("]")[0][1:]
+        _, step, e = ln.split("\t")
+        assert e.startswith("E: ")
+        assert float(e[3:]) == pytest.approx(energies[(phase, int(step))], rel=1e-5 if atol == 0 else 2e-2, abs=atol * 10)
+    if os.path.exists(H5DUMP):          # the coarse chain table of each phase (save_chains, :295-309)
+        for phase in ("spindle", "packing"):
+            d = subprocess.check_output([H5DUMP, "-d", f"/snapshots/{phase}/metadata/chromosome_ranges", "-y", "-w", "200", str(tmp / "traj.h5")], text=True)
+            body = d[d.index("DATA {") + 6:]
+            vals = [int(v) for v in body[:body.index("}")].replace(",", " ").split()]
+            assert vals == [v for (c0, c1, _) in chains for v in (c0, c1)]
+
+
+def test_spindle_driver_on_oracle(tmp_path, oracle):
+    drv = _make_oracle("gd_spindle", tmp_path)
+    _check_spindle(tmp_path, oracle, oracle, drv, atol=0, env=_env(os.path.join(ROOT, "oracle")))
+
+
+@pytest.mark.gpu
+def test_spindle_driver_on_gpu(tmp_path, hip, oracle):
+    _check_spindle(tmp_path, hip, oracle, _make("gd_spindle", ".", "../csrc", "gdyn"), atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------- gd_fine_sampling
+
+FINE_STEPS = 250
+
+
+def _python_fine(lib, oracle, cfg, a, b, ranges, x_restart, ctx_restart):
+    """The ABI call sequence of gd_fine_sampling.cpp from Python."""
+    s = g.System(lib, N, 1)
+    s.set_bead_params(a=a, b=b, mobility=np.full(N, cfg["chromatin_mobility"]))
+    s.set_pair_softcore(cfg["a_core_repulsion"], cfg["a_core_diameter"], cfg["b_core_repulsion"], cfg["b_core_diameter"], 2, 3, 8, 3,
+                        mix=True, scale_by_bead_scale=True)
+    chain = g.System.bond_params(g.POT_SEMISPRING, k_a=cfg["chromatin_bond_spring"], l_a=cfg["chromatin_bond_length"],
+                                 scale_by_bond_scale=True)
+    for (b0, b1) in ranges:
+        s.add_bond_range(chain, b0, b1, 1)
+    semi = np.array(ctx_restart["wall_semiaxes"], dtype=float)
+    s.set_ellipsoid_wall(cfg["a_core_repulsion"], cfg["a_core_diameter"], cfg["b_core_repulsion"], cfg["b_core_diameter"],
+                         cfg["wall_a_factor"], cfg["wall_b_factor"], cfg["wall_packing_spring"], cfg["wall_semiaxes_spring"],
+                         cfg["wall_mobility"], np.array(cfg["wall_init_semiaxes"], dtype=float))
+    s.set_scaling(cfg["bead_scale_init"], cfg["bead_scale_tau"], cfg["bond_scale_init"], cfg["bond_scale_tau"])
+    s.set_positions(x_restart)
+    dt = 1e-5 / 100
+    s.begin_phase(semi)
+    react = np.array(s.context().axial_reaction)
+    s.set_context(0, 0, 1.0, 1.0, semi)
+    out = {0: (s.positions_f32(quantize=True)[0].astype(np.float64), semi.copy(), float(s.energy()[0]) / N)}
+    semi = semi + dt * cfg["wall_mobility"] * (react - np.array(cfg["wall_semiaxes_spring"]) * semi)
+    s.set_context(0, 0, 1.0, 1.0, semi)
+    seed = _mt64(oracle, cfg["interphase_seed"] ^ 700000, 1)
+    step = 0
+    while step < FINE_STEPS:
+        nxt = min(FINE_STEPS, (step // 100 + 1) * 100)
+        if nxt - step > 1:
+            s.run(nxt - step - 1, dt, 0.0, seed=seed, flags=g.RUN_WALL_DYNAMICS)
+        semi = np.array(s.context().semiaxes)
+        s.run(1, dt, 0.0, seed=seed, flags=g.RUN_WALL_DYNAMICS)
+        step = nxt
+        if step % 100 == 0:
+            out[step] = (s.positions_f32(quantize=True)[0].astype(np.float64), semi.copy(), float(s.energy()[0]) / N)
+    assert s.context().bead_scale == 1.0 and s.context().bond_scale == 1.0
+    s.close()
+    return out
+
+
+def _check_fine(tmp, lib, oracle, interphase_driver, fine_driver, atol, env=None):
+    cfg, a, b, x0, ranges, radius = _inputs(tmp)
+    r = subprocess.run([str(interphase_driver), str(tmp / "traj.h5")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    x_restart = _positions(tmp, "interphase", INTER)
+    ctx_restart = json.loads(_tool("context", tmp / "traj.h5", "interphase", INTER))
+    r = subprocess.run([str(fine_driver), str(tmp / "traj.h5"), "0", str(INTER)], capture_output=True, text=True,
+                       env=dict(env or os.environ, GD_FINE_STEPS=str(FINE_STEPS)))
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[fine]")]
+    assert len(lines) == FINE_STEPS // cfg["interphase_logging_interval"] + 1
+    assert _tool("steps", tmp / "traj.h5", "fine_sampling").split() == ["0", "100", "200"]    # sampling interval forced to 100
+    ref = _python_fine(lib, oracle, cfg, a, b, ranges, x_restart, ctx_restart)
+    for step, (pos, semi, e) in ref.items():
+        got = _positions(tmp, "fine_sampling", step)
+        assert np.abs(got - pos).max() <= atol, step
+        c = json.loads(_tool("context", tmp / "traj.h5", "fine_sampling", step))
+        assert c["time"] == pytest.approx(step * 1e-7, abs=1e-18)
+        assert c["bead_scale"] == 1.0 and c["bond_scale"] == 1.0               # simulation_driver.cc:55-56
+        assert np.allclose(c["wall_semiaxes"], semi, rtol=0, atol=max(atol * 1e-3, 1e-12))
+        assert c["mean_energy"] == pytest.approx(e, rel=1e-12 if atol == 0 else 1e-3)
+    # T = 0: deterministic descent, the energy does not increase between samples
+    es = [ref[k][2] for k in sorted(ref)]
+    assert all(e1 <= e0 + 1e-9 for e0, e1 in zip(es, es[1:]))
+
+
+def test_fine_sampling_driver_on_oracle(tmp_path, oracle):
+    env = _env(os.path.join(ROOT, "oracle"))
+    _check_fine(tmp_path, oracle, oracle, _make_oracle("gd_interphase", tmp_path), _make_oracle("gd_fine_sampling", tmp_path), atol=0, env=env)
+
+
+@pytest.mark.gpu
+def test_fine_sampling_driver_on_gpu(tmp_path, hip, oracle):
+    _check_fine(tmp_path, hip, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), _make("gd_fine_sampling", ".", "../csrc", "gdyn"), atol=2e-4)
