@@ -15,6 +15,8 @@
 #pragma once
 #include <hdf5.h>
 
+#include "gd_h5util.hpp"
+
 #include <array>
 #include <cstdint>
 #include <map>
@@ -37,7 +39,6 @@ struct context {   // simulation_common/simulation_context.hpp
     double mean_energy = 0, wall_energy = 0;
 };
 
-class h5_error : public std::runtime_error { using std::runtime_error::runtime_error; };
 
 class trajectory_store {
 public:

@@ -25,12 +25,22 @@ PKG = "2022a-genome-dynamics_amd"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
-    """The oracle (CPU restatement, reference flags -O2 -msse4 -mno-avx, single thread, fp64,
-    mt19937_64 normals like the reference's RNG class) timed on this host: 1 replica of the same
-    workload, starting from the GPU-equilibrated positions."""
-    path = os.path.join(ROOT, "oracle", "liboracle.so")
-    orc = g.Lib(path)
+_FARM_WORKER = r"""
+import importlib, sys, time, numpy as np
+root, lib, npy, n_beads, steps, seed = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+sys.path.insert(0, root)
+g = importlib.import_module("2022a-genome-dynamics_amd"); wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
+s, _ = wl.genome_interphase(g.Lib(lib), n_beads=n_beads, n_replicas=1)
+s.set_positions(np.load(npy)[None]); s.begin_phase()
+flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+s.run(5, 1e-5, 1.0, seed=seed, noise=g.NOISE_MT19937, flags=flags)
+print("ready", flush=True); sys.stdin.readline()
+t0 = time.perf_counter(); s.run(steps, 1e-5, 1.0, seed=seed, noise=g.NOISE_MT19937, flags=flags); print(time.perf_counter() - t0, flush=True)
+"""
+
+
+def _oracle_rate(g, wl, lib_path, x0, n_beads, budget_s):
+    orc = g.Lib(lib_path)
     s, _ = wl.genome_interphase(orc, n_beads=n_beads, n_replicas=1)
     s.set_positions(x0[None])
     s.begin_phase()
@@ -43,9 +53,49 @@ def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
     s.run(steps, 1e-5, 1.0, seed=2, noise=g.NOISE_MT19937, flags=flags)
     el = time.perf_counter() - t0
     s.close()
-    return {"value": n_beads * steps / el, "unit": "bead-steps/s", "cores": 1, "kind": "port",
+    return steps, el
+
+
+def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
+    """The oracle (CPU restatement, single thread, fp64, Verlet list, mt19937_64 normals like the reference's
+    RNG class) timed on this host on the same workload, starting from the GPU-equilibrated positions:
+    (i) 1 core with the reference's flags (-O2 -msse4 -mno-avx, 5-sim-genome/Makefile:7-12) -- faithful to the
+    single-threaded reference; (ii) SURVEY 8d's farm comparison: one independent replica per host thread with the
+    -O3 build.  Returns (cpu_baseline, farm) -- `farm` is extra information, not the contract's baseline."""
+    import subprocess
+    import tempfile
+    steps, el = _oracle_rate(g, wl, os.path.join(ROOT, "oracle", "liboracle.so"), x0, n_beads, budget_s)
+    base = {"value": n_beads * steps / el, "unit": "bead-steps/s", "cores": 1, "kind": "port",
             "sample": f"{steps} steps of 1 replica x {n_beads} beads (oracle/liboracle.so, fp64, Verlet list, "
                       f"mt19937_64 normals, flags -O2 -march=x86-64 -msse4 -mno-avx), {el:.1f} s on 1 of {os.cpu_count()} host threads"}
+    farm = None
+    fast = os.path.join(ROOT, "oracle", "liboracle_fast.so")
+    try:
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        if os.path.exists(fast) and cores > 1:
+            fsteps, fel = _oracle_rate(g, wl, fast, x0, n_beads, 2.0)
+            fsteps = int(max(10, budget_s * 0.6 * fsteps / fel))      # the loaded machine runs slower than the 1-core probe
+            with tempfile.TemporaryDirectory() as tmp:
+                npy = os.path.join(tmp, "x0.npy")
+                np.save(npy, x0)
+                procs = [subprocess.Popen([sys.executable, "-c", _FARM_WORKER, ROOT, fast, npy, str(n_beads), str(fsteps), str(100 + k)],
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for k in range(cores)]
+                for p in procs:
+                    assert p.stdout.readline().strip() == "ready"
+                t0 = time.perf_counter()
+                for p in procs:
+                    p.stdin.write("go\n"); p.stdin.flush()
+                times = [float(p.stdout.readline()) for p in procs]
+                wall = time.perf_counter() - t0
+                for p in procs:
+                    p.wait()
+            farm = {"value": cores * n_beads * fsteps / wall, "unit": "bead-steps/s", "cores": cores, "kind": "port",
+                    "one_core_value": n_beads * fsteps / min(times),
+                    "sample": f"{cores} processes x {fsteps} steps of 1 replica x {n_beads} beads (oracle/liboracle_fast.so, "
+                              f"-O3 -march=x86-64-v3), {wall:.1f} s wall"}
+    except (OSError, ValueError, AssertionError) as e:
+        farm = {"error": repr(e)}
+    return base, farm
 
 
 def main():
@@ -157,11 +207,16 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kms,
+                         # the list length is a tuning choice (skin); the same rate priced at SURVEY 8d's reference
+                         # list (L = 5.7 N, 204 B per bead-step) over the WHOLE step (rebuilds included):
+                         "whole_step_frac_at_survey_list": 204.0 * N * R * a.steps / el / 1e9 / HBM_PEAK_GBS,
                          "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},
         }
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(g, wl, sys_.positions()[0], N)
+            out["cpu_baseline"], farm_cpu = cpu_baseline(g, wl, sys_.positions()[0], N)
             out["config"]["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+            if farm_cpu is not None:
+                out["config"]["cpu_farm_all_host_threads"] = farm_cpu
         print(json.dumps(out), flush=True)
     sys_.close()
     if world > 1:
