@@ -6,6 +6,8 @@
 //   gd_h5tool positions <file> <phase> <step> <out.f64>
 //   gd_h5tool context <file> <phase> <step>            prints the JSON context fields
 //   gd_h5tool contacts <file> <phase> <step>           prints "i j count" rows
+//   gd_h5tool dataset <file> <path> <out.f64>          any numeric dataset as raw doubles; prints its shape
+//   gd_h5tool strings <file> <path>                    a string dataset (scalar or 1-d), one item per line
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -91,7 +93,38 @@ int main(int argc, char **argv)
             for (hsize_t k = 0; k < dims[0]; k++) std::cout << v[3 * k] << ' ' << v[3 * k + 1] << ' ' << v[3 * k + 2] << '\n';
             return 0;
         }
-        std::cerr << "usage: gd_h5tool make-input|steps|positions|context|contacts ...\n";
+        if (cmd == "dataset" && argc == 5) {
+            hid_t f = H5Fopen(argv[2], H5F_ACC_RDONLY, H5P_DEFAULT);
+            hid_t ds = H5Dopen2(f, argv[3], H5P_DEFAULT);
+            if (f < 0 || ds < 0) throw std::runtime_error(std::string("no dataset ") + argv[3]);
+            hid_t sp = H5Dget_space(ds);
+            hsize_t dims[8] = {0};
+            int const nd = H5Sget_simple_extent_dims(sp, dims, nullptr);
+            hsize_t count = 1;
+            for (int k = 0; k < nd; k++) { count *= dims[k]; std::cout << dims[k] << (k + 1 < nd ? " " : "\n"); }
+            std::vector<double> v(count);
+            if (count && H5Dread(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, v.data()) < 0) throw std::runtime_error("cannot read dataset");
+            std::ofstream out(argv[4], std::ios::binary);
+            out.write(reinterpret_cast<char const *>(v.data()), (std::streamsize)(count * sizeof(double)));
+            return 0;
+        }
+        if (cmd == "strings" && argc == 4) {
+            hid_t f = H5Fopen(argv[2], H5F_ACC_RDONLY, H5P_DEFAULT);
+            std::string const path = argv[3];
+            auto const cut = path.rfind('/');
+            hid_t loc = cut == std::string::npos || cut == 0 ? H5Gopen2(f, "/", H5P_DEFAULT) : H5Gopen2(f, path.substr(0, cut).c_str(), H5P_DEFAULT);
+            if (f < 0 || loc < 0) throw std::runtime_error("no such group");
+            std::string const name = cut == std::string::npos ? path : path.substr(cut + 1);
+            hid_t ds = H5Dopen2(loc, name.c_str(), H5P_DEFAULT);
+            if (ds < 0) throw std::runtime_error("no dataset " + path);
+            hid_t sp = H5Dget_space(ds);
+            bool const scalar = H5Sget_simple_extent_type(sp) == H5S_SCALAR;
+            H5Sclose(sp); H5Dclose(ds);
+            if (scalar) std::cout << gd::h5::read_string(loc, name) << '\n';
+            else for (auto const &s : gd::h5::read_string_list(loc, name)) std::cout << s << '\n';
+            return 0;
+        }
+        std::cerr << "usage: gd_h5tool make-input|steps|positions|context|contacts|dataset|strings ...\n";
         return 1;
     } catch (std::exception const &e) {
         std::cerr << "error: " << e.what() << '\n';

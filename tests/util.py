@@ -35,3 +35,58 @@ def build(lib, name, **over):
 
 def force_scale(sys_):
     return float(np.abs(sys_.forces(g.TERM_ALL)).max())
+
+
+# ---- std::mt19937_64 and libstdc++ distributions, for the drivers' initial conditions
+import ctypes as C
+
+
+def mt64(oracle, seed, n):
+    f = oracle.dll.oracle_mt64_nth
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_uint64, C.c_int]
+    return f(seed, n)
+
+
+
+class Mt64:
+    """std::mt19937_64 draws through the oracle's generator, plus libstdc++'s std::normal_distribution<double>
+    (Marsaglia polar method on generate_canonical<double, 53>: one 64-bit draw per uniform) -- what
+    simulation_spindle/simulation_driver.cc:189-199 consumes from `_random`."""
+
+    def __init__(self, oracle, seed):
+        self.oracle, self.seed, self.n = oracle, seed, 0
+
+    def draw(self):
+        self.n += 1
+        return mt64(self.oracle, self.seed, self.n)
+
+    def canonical(self):
+        r = float(self.draw()) / 18446744073709551616.0
+        return r if r < 1.0 else float(np.nextafter(1.0, 0.0))
+
+    def uniform(self, a, b):
+        """One draw of a std::uniform_real_distribution<double>{a, b}."""
+        return self.canonical() * (b - a) + a
+
+    def normals(self, count):
+        """`count` values from a freshly constructed distribution object."""
+        import math
+        out, saved = [], None
+        while len(out) < count:
+            if saved is not None:
+                out.append(saved)
+                saved = None
+                continue
+            while True:
+                x = 2.0 * self.canonical() - 1.0
+                y = 2.0 * self.canonical() - 1.0
+                r2 = x * x + y * y
+                if not (r2 > 1.0 or r2 == 0.0):
+                    break
+            mult = math.sqrt(-2 * math.log(r2) / r2)
+            saved = x * mult
+            out.append(y * mult)
+        return out
+
+
