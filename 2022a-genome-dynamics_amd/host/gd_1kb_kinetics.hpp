@@ -78,7 +78,9 @@ public:
     // loads the steady-state expectation loading/unloading of loops at uniformly random sites
     void preload(rng &random)
     {
-        auto const expected = std::size_t(_load / _unload);
+        double const ratio = _load / _unload;
+        if (!std::isfinite(ratio) || ratio < 0) return;      // unloading rate 0: undefined in the reference (size_t(NaN or inf))
+        auto const expected = std::size_t(ratio);
         std::uniform_int_distribution<std::size_t> pick{0, chain_length() - 1};
         for (std::size_t k = 0; k < expected; k++) {
             auto const pos = pick(random);
