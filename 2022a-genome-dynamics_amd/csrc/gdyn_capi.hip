@@ -94,7 +94,7 @@ struct gd_system {
     int pcur = 0, ccur = 0;
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
-    uint32_t cpb = 1, tile_cap = 3072;
+    uint32_t cpb = 1, tile_cap = 3280;
 
     // tuning / cadence
     double skin = 0.8;
@@ -634,6 +634,17 @@ static int read_flags(gd_system *s, std::vector<unsigned> &f)
 }
 static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (size_t)s->R * GD_NFLAGS * sizeof(unsigned), s->stream)); return GD_OK; }
 
+// Tile capacities (float4 entries) at which k_step still fits 3, 2, 1 blocks into the 160 KB of LDS of a CU
+// (1.2 KB static LDS per block on top of the tile).
+static unsigned pick_tile_cap(unsigned need)
+{
+    static unsigned caps[3] = {3280u, 5040u, 8192u};   // LDS is granted in 1280-byte granules (measured: 3264 fits 3 blocks, 3318 does not)
+    static bool init = false;
+    if (!init) { if (const char *e = getenv("GDYN_TILE_CAP3")) caps[0] = (unsigned)atoi(e); init = true; }   // experiment hook
+    for (unsigned c : caps) if (need <= c) return c;
+    return need;     // > 8192: the caller falls back to the generic path
+}
+
 // React to list-width / tile-capacity overflow flags: widen the list, enlarge the LDS tile or
 // fall back to the generic path. Returns true when a build has to be redone.
 static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
@@ -645,11 +656,16 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     }
     if (!tover && !over && s->list_tiled && need_t > 0) {
         // size the LDS tile to what the builds actually need (more resident blocks per CU)
-        const unsigned want = std::min(8192u, need_t + need_t / 6 + 64);
-        if (want > s->tile_cap || want + want / 4 < s->tile_cap) s->tile_cap = want;
+        // LDS capacity is a step function of the tile size: k_step keeps 3 / 2 / 1 blocks (6 / 4 / 2 waves per SIMD)
+        // resident per CU up to these tile capacities, so the capacity is always the largest one of its occupancy class
+        const unsigned want = pick_tile_cap(need_t + need_t / 50 + 16);
+        if (want != s->tile_cap && want <= 8192u) {
+            if (getenv("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
+            s->tile_cap = want;
+        }
     }
     if (tover) {
-        const unsigned cap = need_t + need_t / 8 + 64;
+        const unsigned cap = pick_tile_cap(need_t + need_t / 16 + 32);
         if (cap <= 8192) s->tile_cap = cap;    // 128 KB dynamic + static part < 160 KB of LDS per CU
         else s->tiled_ok = false;                // too dense for one tile: generic path
     }
@@ -933,6 +949,7 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
     p.dt_d = 1e-5; p.dt = 1e-5f; p.kT = 1.0f; p.seed = 1; p.noise_mode = GD_NOISE_PHILOX; p.run_flags = 0;
     p.ctx_out = s->ctx[s->ccur ^ 1].p;     // scratch: the current context is not replaced
     GDCHK(clear_flags(s));
+    if (what >= 10) HIPCHK(hipMemsetAsync(s->fout.p, 0, s->fout.n * sizeof(float4), s->stream));
     HIPCHK(hipEventRecord(e0, s->stream));
     for (int i = 0; i < n; i++) {
         if (what == 0) { GDCHK(enqueue_build(s, rv, pair_cutoff(s) > 0)); }
@@ -944,6 +961,17 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *mean_ms = ms / n;
+    if (what >= 10) {
+        // section stamps of a timing-only kernel build (-DGD_ABL=30): mean shader-clock cycles per wave spent in
+        // section what-10 (zeros with the product kernels, which never write the force buffer in step mode)
+        // (one 8-word record per wave: 7 section times of the last launch + a presence flag)
+        std::vector<unsigned long long> rec(std::min<size_t>(s->fout.n * 2, (size_t)1 << 22));
+        HIPCHK(hipMemcpy(rec.data(), s->fout.p, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum = 0, waves = 0;
+        for (size_t w = 0; w + 8 <= rec.size(); w += 8)
+            if (rec[w + 7] == 1ull && what - 10 < 7) { sum += (double)rec[w + what - 10]; waves += 1; }
+        *mean_ms = waves > 0 ? sum / waves : 0.0;
+    }
     GDCHK(clear_flags(s));
     return GD_OK;
 }

@@ -230,6 +230,13 @@ struct CtxF {
 };
 
 // ------------------------------------------------------------------- k_step
+// GD_ABL == 30 (timing-only build): per-section shader-clock stamps, summed per wave into the (otherwise unused in
+// step mode) force-output buffer; read back by gd_debug_bench(what >= 10).
+#if GD_ABL == 30
+#define GD_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] = now_ - tprev_; tprev_ = now_; } while (0)
+#else
+#define GD_STAMP(k) do { } while (0)
+#endif
 
 // TILED: the block first stages its LDS tile (its own 256 slots + all slots of the adjacent
 // cells, 9 contiguous slot ranges, TileDesc) with coalesced loads; pair-list entries are 16-bit
@@ -254,6 +261,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     // so their latencies overlap (the kernel is latency-bound, not ALU-bound)
     // thread -> bead assignment: the build sorted each block's beads by pair-list length, so the 64 lanes
     // of a wave run (almost) the same number of list batches instead of waiting for their longest list
+#if GD_ABL == 30
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime(), acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const unsigned slot = blk * GD_BLOCK + p.perm[rbase + blk * GD_BLOCK + tid];
     const bool valid = slot < p.N;
     const size_t g = rbase + slot;
@@ -312,7 +322,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             s_ctx.step = c.step;
         }
     }
+    GD_STAMP(0);      // prologue: loads issued, tile DMA issued, noise
     __syncthreads();
+    GD_STAMP(1);      // barrier (tile arrival)
 
     const unsigned mask = (MODE == GD_MODE_STEP) ? 63u : p.term_mask;
 
@@ -368,7 +380,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                     jj[0] = q0.x; jj[1] = q0.y; jj[2] = q0.z; jj[3] = q0.w; jj[4] = q1.x; jj[5] = q1.y; jj[6] = q1.z; jj[7] = q1.w;
                 }
 #pragma unroll
-                for (int u = 0; u < GD_UNROLL; u++) xjv[u] = TILED ? s_tile[jj[u]] : rpos[jj[u]];
+                for (int u = 0; u < GD_UNROLL; u++) {
+                    if (GD_ABL == 22) xjv[u] = s_tile[(threadIdx.x + 64u * u + k0) & 2047u];          // conflict-free LDS reads
+                    else if (GD_ABL == 23) xjv[u] = make_float4(xi.x + 0.01f * (float)(jj[u] & 15u), xi.y + 0.02f, xi.z, xi4.w);   // no LDS
+                    else xjv[u] = TILED ? s_tile[jj[u]] : rpos[jj[u]];
+                }
 #pragma unroll
                 for (int u = 0; u < GD_UNROLL; u++) {
                     const float4 xj = xjv[u];
@@ -384,7 +400,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                             waca = fmaf(abj.x, hca, Ai); wbcb = fmaf(abj.y, hcb, Bi);      // (a_i+a_j)/2 * ca, (b_i+b_j)/2 * cb
                             if (MODE == GD_MODE_ENERGY) { wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y); }
                         }
-                        const float f = softcore_2383(r2, inv_sa2, inv_sb2, waca, wbcb);
+                        const float f = GD_ABL == 21 ? waca * fmaxf(fmaf(-r2, inv_sa2, 1.0f), 0.0f)
+                                      : GD_ABL == 24 ? r2 : softcore_2383(r2, inv_sa2, inv_sb2, waca, wbcb);
                         F.x = fmaf(f, d.x, F.x); F.y = fmaf(f, d.y, F.y); F.z = fmaf(f, d.z, F.z);
                         if (MODE == GD_MODE_ENERGY && k0 + u < cnt)
                             E += 0.5f * softcore_2383_energy(r2, inv_sa2, inv_sb2, p.pair.eps_a, p.pair.eps_b, wa, wb);
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             }
         }
 
+        GD_STAMP(2);  // pair loop
         // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
         if (GD_ABL != 13 && p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
             const unsigned deg = meta & 0xffu;
@@ -434,6 +452,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             }
         }
 
+        GD_STAMP(3);  // bonds
         // ---- cosine bending over the (up to) three triplets this bead belongs to (a7)
         if (p.has_bend && (mask & TERM_BEND)) {
             const float4 be = p.bendE[g];
@@ -485,6 +504,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             }
         }
 
+        GD_STAMP(4);  // bending + point sources
         // ---- ellipsoid wall (a9): second-order nearest-surface construction
         // (5-sim-genome/src/analyze_lamina/geometry.py:13-28), conjugate form u = C/(B+sqrt(B^2-AC)).
         if (GD_ABL != 15 && p.wall.enabled && (mask & TERM_WALL)) {
@@ -524,6 +544,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         }
 
         if (MODE == GD_MODE_STEP) {
+            GD_STAMP(5);  // wall
             // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
             const float mu_dt = mu * p.dt;
             const float sg = sqrtf(2.0f * p.kT * mu_dt);
@@ -534,6 +555,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         }
     }
 
+    GD_STAMP(6);      // integrate + store
+#if GD_ABL == 30
+    if ((threadIdx.x & 63) == 0) {      // one record per wave, plain stores
+        unsigned long long *rec = (unsigned long long *)p.fout + ((size_t)blockIdx.x * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 8;
+        for (int k = 0; k < 7; k++) rec[k] = acc_[k];
+        rec[7] = 1ull;
+    }
+#endif
     // ---- block reductions: wall reaction partial (deterministic), energy, max displacement
     if (p.wall.enabled && MODE != GD_MODE_ENERGY) {
         const float sx = wave_sum_f(react.x), sy = wave_sum_f(react.y), sz = wave_sum_f(react.z);
