@@ -103,6 +103,7 @@ struct gd_system {
     uint32_t steps_since_build = 0;
     float rv = 0;
     uint64_t rebuilds = 0, rollbacks = 0;
+    uint32_t n_bond_types = 0;
     std::vector<unsigned long long> lcount;
     gd_timing timing{};
 
@@ -507,7 +508,7 @@ static int finalize_topology(gd_system *s)
     s->packed_ab = packable;
 
     HIPCHK(s->ab_o.resize(N)); HIPCHK(s->mob_o.resize(N)); HIPCHK(s->bendE_o.resize(N)); HIPCHK(s->psmask_o.resize(N));
-    HIPCHK(s->bdeg_o.resize(N)); HIPCHK(s->badj_o.resize(adj.size())); HIPCHK(s->chain_o.resize(N)); HIPCHK(s->btab.resize(bt.size()));
+    HIPCHK(s->bdeg_o.resize(N)); HIPCHK(s->badj_o.resize(adj.size())); HIPCHK(s->chain_o.resize(N)); HIPCHK(s->btab.resize(GD_MAX_BOND_TYPES));   /* always the full 1 KiB table: k_step stages it with one DMA piece */
     HIPCHK(hipMemcpy(s->ab_o.p, ab.data(), N * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->mob_o.p, mob.data(), N * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->bendE_o.p, bendE.data(), N * sizeof(float4), hipMemcpyHostToDevice));
@@ -515,7 +516,9 @@ static int finalize_topology(gd_system *s)
     HIPCHK(hipMemcpy(s->bdeg_o.p, dg.data(), N, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->badj_o.p, adj.data(), adj.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->chain_o.p, chain.data(), N * sizeof(int4), hipMemcpyHostToDevice));
+    if (bt.size() > GD_MAX_BOND_TYPES) return fail(GD_EINVAL, "too many bond types");
     HIPCHK(hipMemcpy(s->btab.p, bt.data(), bt.size() * sizeof(BondType), hipMemcpyHostToDevice));
+    s->n_bond_types = (uint32_t)bt.size();
     const size_t RNp = (size_t)s->R * s->Np;
     const uint32_t WBp = std::max((WB + 3u) & ~3u, 4u);      // adjacency width in entries, chunks of 4
     if (WBp != s->WB || !s->badj.p) { HIPCHK(s->badj.resize((size_t)WBp * RNp)); }
@@ -571,7 +574,7 @@ static void fill_common(gd_system *s, StepParams &p)
         p.wall.mobility = w.mobility;
     }
     p.scaling = ScaleP{s->has_scaling ? 1 : 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau};
-    p.btab = s->btab.p; p.nbt = (int)(s->btab.n);
+    p.btab = s->btab.p; p.nbt = (int)s->n_bond_types;
     p.nps = (int)s->psrc.size();
     for (int q = 0; q < p.nps; q++) {
         p.ps[q].kind = s->psrc[q].kind; p.ps[q].k = (float)s->psrc[q].k; p.ps[q].b = (float)s->psrc[q].b;
@@ -638,9 +641,13 @@ static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (siz
 // (1.2 KB static LDS per block on top of the tile).
 static unsigned pick_tile_cap(unsigned need)
 {
-    static unsigned caps[3] = {3280u, 5040u, 8192u};   // LDS is granted in 1280-byte granules (measured: 3264 fits 3 blocks, 3318 does not)
+    // LDS is granted in 1280-byte granules (measured: 3264 entries fit 3 blocks, 3318 do not)
+    static std::vector<unsigned> caps = {3280u, 5040u, 8192u};
     static bool init = false;
-    if (!init) { if (const char *e = getenv("GDYN_TILE_CAP3")) caps[0] = (unsigned)atoi(e); init = true; }   // experiment hook
+    if (!init) {      // experiment hook: GDYN_TILE_CAPS=a,b,c
+        if (const char *e = getenv("GDYN_TILE_CAPS")) { caps.clear(); for (const char *q = e; *q;) { caps.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
+        init = true;
+    }
     for (unsigned c : caps) if (need <= c) return c;
     return need;     // > 8192: the caller falls back to the generic path
 }
@@ -968,8 +975,8 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
         std::vector<unsigned long long> rec(std::min<size_t>(s->fout.n * 2, (size_t)1 << 22));
         HIPCHK(hipMemcpy(rec.data(), s->fout.p, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double sum = 0, waves = 0;
-        for (size_t w = 0; w + 8 <= rec.size(); w += 8)
-            if (rec[w + 7] == 1ull && what - 10 < 7) { sum += (double)rec[w + what - 10]; waves += 1; }
+        for (size_t w = 0; w + 16 <= rec.size(); w += 16)
+            if (rec[w + 15] == 1ull && what - 10 < 12) { sum += (double)rec[w + what - 10]; waves += 1; }
         *mean_ms = waves > 0 ? sum / waves : 0.0;
     }
     GDCHK(clear_flags(s));

@@ -262,9 +262,42 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     // thread -> bead assignment: the build sorted each block's beads by pair-list length, so the 64 lanes
     // of a wave run (almost) the same number of list batches instead of waiting for their longest list
 #if GD_ABL == 30
-    unsigned long long tprev_ = __builtin_amdgcn_s_memtime(), acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime(), acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    const unsigned slot = blk * GD_BLOCK + p.perm[rbase + blk * GD_BLOCK + tid];
+    // ---- prologue, ordered for the in-order vmcnt counter: first everything that does not depend on the thread->bead
+    // permutation (bond table and tile go straight into LDS by DMA, nothing returns to registers), then the perm load
+    // and the per-bead loads; the noise then waits for the youngest loads only (a static vmcnt).
+    if (TILED && GD_ABL != 12 && (GD_ABL != 33 || (blk & 3u) == 0)) {
+        // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
+        // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
+        // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
+        const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
+        // the whole descriptor is fetched first, with scalar loads: a descriptor read placed after a DMA (which the
+        // compiler must treat as a store) becomes a per-lane vector load behind a full vmcnt(0) wait -- once per range
+        unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
+#pragma unroll
+        for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = td->len[k]; tst[k] = td->start[k]; tbase[k] = td->base[k]; }
+        if (wid == 0)       // the bond-type table (GD_MAX_BOND_TYPES x 32 B = one 1 KiB piece; the buffer is always that large)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)p.btab + lane),
+                                             (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < GD_TILE_RANGES; k++) {
+            const unsigned len = tlen[k], st = tst[k], base = tbase[k];
+            for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
+                if (q0 + lane < len)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
+                                                     (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
+            }
+        }
+    } else {
+        for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
+    }
+    GD_STAMP(11);     // descriptor + DMA issue
+    const unsigned slot = blk * GD_BLOCK + (GD_ABL == 31 ? tid : (unsigned)p.perm[rbase + blk * GD_BLOCK + tid]);
+#if GD_ABL == 30
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GD_STAMP(7);      // perm arrived
+#endif
     const bool valid = slot < p.N;
     const size_t g = rbase + slot;
     const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
@@ -282,22 +315,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         if (p.has_bonds) adj0 = adj[0];
         if (p.pair.enabled) { qa = lst[0]; if (!TILED) qb = lst[64]; }
     }
-    for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
-    if (TILED && GD_ABL != 12) {
-        // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
-        // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
-        // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
-        const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
-#pragma unroll
-        for (int k = 0; k < GD_TILE_RANGES; k++) {
-            const unsigned len = td->len[k], st = td->start[k], base = td->base[k];
-            for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
-                if (q0 + lane < len)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
-                                                     (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
-            }
-        }
-    }
+    GD_STAMP(8);      // bead loads, bond table, tile DMA issued
+#if GD_ABL == 30
+    asm volatile("" :: "v"(oid));
+    GD_STAMP(9);      // oid arrived
+#endif
     // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
     // and the per-bead loads are in flight (the step index comes from a uniform scalar load)
     float3 z = make_float3(0.f, 0.f, 0.f);
@@ -310,6 +332,10 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             z = make_float3(h[0], h[1], h[2]);
         }
     }
+#if GD_ABL == 30
+    asm volatile("" :: "v"(z.x), "v"(z.y), "v"(z.z));
+    GD_STAMP(10);     // noise
+#endif
     if (wid == 0) {
         DevCtx c = p.ctx_in[r];
         if (MODE == GD_MODE_STEP) {
@@ -426,29 +452,43 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         if (GD_ABL != 13 && p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
             const unsigned deg = meta & 0xffu;
             const float inv_bs2 = 1.0f / (s_ctx.bond_scale * s_ctx.bond_scale);
-            uint4 aq = adj0;
-            for (unsigned k = 0; k < deg; k++) {
-                if (k && (k & 3u) == 0) aq = adj[(size_t)(k >> 2) * 64];
-                const unsigned ent = (k & 3u) == 0 ? aq.x : (k & 3u) == 1 ? aq.y : (k & 3u) == 2 ? aq.z : aq.w;
-                const unsigned j = ent & GD_ADJ_MASK;
-                const BondType bt = s_bt[(ent >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1)];
-                if (!(mask & (unsigned)bt.term)) continue;
-                float4 xj;
-                if (TILED && (ent & GD_ADJ_LOCAL)) xj = s_tile[j]; else xj = rpos[j];
-                float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
-                if (PERIODIC && (bt.flags & 4)) d = min_image(d, p.box, p.inv_box);
-                const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                float K = bt.ka, l = bt.la;
-                if (bt.flags & 1) {
-                    const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
-                    const float a = 0.5f * (abi.x + abj.x), b = 0.5f * (abi.y + abj.y);
-                    K = a * bt.ka + b * bt.kb; l = a * bt.la + b * bt.lb;
+            // four adjacency entries (one 16-byte chunk) per round: the partner positions are fetched together, so
+            // their LDS / global latencies overlap instead of adding up bond by bond
+            for (unsigned k0 = 0; k0 < deg; k0 += 4) {
+                const uint4 aq = k0 == 0 ? adj0 : adj[(size_t)(k0 >> 2) * 64];
+                const unsigned ents[4] = {aq.x, aq.y, aq.z, aq.w};
+                float4 xjs[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    xjs[u] = xi4;
+                    if (k0 + u < deg) {
+                        const unsigned j = ents[u] & GD_ADJ_MASK;
+                        if (TILED && (ents[u] & GD_ADJ_LOCAL)) xjs[u] = s_tile[j]; else xjs[u] = rpos[j];
+                    }
                 }
-                if (bt.flags & 2) { K = K * inv_bs2; l = l * s_ctx.bond_scale; }
-                float e, fr;
-                bond_pot(bt.kind, K, l, bt.pq & 0xff, bt.pq >> 8, r2, e, fr);
-                F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
-                if (MODE == GD_MODE_ENERGY) E += 0.5f * e;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (k0 + u >= deg) break;
+                    const unsigned ent = ents[u];
+                    const unsigned j = ent & GD_ADJ_MASK;
+                    const BondType bt = s_bt[(ent >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1)];
+                    if (!(mask & (unsigned)bt.term)) continue;
+                    const float4 xj = xjs[u];
+                    float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+                    if (PERIODIC && (bt.flags & 4)) d = min_image(d, p.box, p.inv_box);
+                    const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                    float K = bt.ka, l = bt.la;
+                    if (bt.flags & 1) {
+                        const float2 abj = (TILED || p.packed_ab) ? unpack_ab(xj.w) : rab[j];
+                        const float a = 0.5f * (abi.x + abj.x), b = 0.5f * (abi.y + abj.y);
+                        K = a * bt.ka + b * bt.kb; l = a * bt.la + b * bt.lb;
+                    }
+                    if (bt.flags & 2) { K = K * inv_bs2; l = l * s_ctx.bond_scale; }
+                    float e, fr;
+                    bond_pot(bt.kind, K, l, bt.pq & 0xff, bt.pq >> 8, r2, e, fr);
+                    F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
+                    if (MODE == GD_MODE_ENERGY) E += 0.5f * e;
+                }
             }
         }
 
@@ -512,6 +552,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                         ic = 1.0f / (s_ctx.semi[2] * s_ctx.semi[2]);
             const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);
             const float C = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z - 1.0f;
+            // A bead on the level set s E (s = sqrt(C+1) < 1) is at least (1-s) min(a,b,c) away from the surface
+            // (E contains s E + (1-s) min(a,b,c) B), so beyond half the larger wall diameter the force is exactly zero:
+            // waves of interior beads (the slots are cell-sorted) skip the nearest-point construction altogether.
+            const float reach = 0.5f * fmaxf(p.wall.sigma_a, p.wall.sigma_b) * (p.wall.scaled ? s_ctx.bead_scale : 1.0f);
+            const float smin = fminf(s_ctx.semi[0], fminf(s_ctx.semi[1], s_ctx.semi[2]));
+            const float sthr = 1.0f - reach / smin;
+            const bool near_wall = !(sthr > 0.f) || C + 1.0f >= sthr * sthr * 0.999f;
+            if (__builtin_amdgcn_ballot_w64(near_wall) != 0ull) {
             const float B = s1.x * s1.x + s1.y * s1.y + s1.z * s1.z;
             const float A = s1.x * s1.x * ia + s1.y * s1.y * ib + s1.z * s1.z * ic;
             const float den = B + sqrtf(fmaxf(B * B - A * C, 0.f));
@@ -541,6 +589,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                 }
                 if (MODE == GD_MODE_ENERGY) E += e;
             }
+            }
         }
 
         if (MODE == GD_MODE_STEP) {
@@ -558,9 +607,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     GD_STAMP(6);      // integrate + store
 #if GD_ABL == 30
     if ((threadIdx.x & 63) == 0) {      // one record per wave, plain stores
-        unsigned long long *rec = (unsigned long long *)p.fout + ((size_t)blockIdx.x * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 8;
-        for (int k = 0; k < 7; k++) rec[k] = acc_[k];
-        rec[7] = 1ull;
+        unsigned long long *rec = (unsigned long long *)p.fout + ((size_t)blockIdx.x * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 16;
+        for (int k = 0; k < 12; k++) rec[k] = acc_[k];
+        rec[15] = 1ull;
     }
 #endif
     // ---- block reductions: wall reaction partial (deterministic), energy, max displacement
@@ -862,14 +911,14 @@ __global__ void k_tiles(const BuildParams p)
             atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total + len);
             len = 0; truncated = true;
         }
-        td.start[k] = st; td.len[k] = (unsigned short)len; td.base[k] = (unsigned short)total;
+        td.start[k] = st; td.len[k] = len; td.base[k] = total;
         total += len;
     }
     for (int k = 0; k < GD_TILE_RANGES; k++) {
         td.kstart[k] = 0xffffffffu; td.kbase[k] = 0;
         if (kin[k] >= 0 && !truncated) {
             const unsigned ks = cs[klo[k]];
-            td.kstart[k] = ks; td.kbase[k] = (unsigned short)(td.base[kin[k]] + (ks - td.start[kin[k]]));
+            td.kstart[k] = ks; td.kbase[k] = td.base[kin[k]] + (ks - td.start[kin[k]]);
         }
     }
     td.nranges = truncated ? 0u : (unsigned)nm;

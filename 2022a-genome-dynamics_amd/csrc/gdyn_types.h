@@ -13,7 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef GD_BLOCK
 #define GD_BLOCK 512
+#endif
 #define GD_MAX_BOND_TYPES 32
 #define GD_MAX_POINT_SOURCES 4
 #define GD_ADJ_SHIFT 26                    // bond adjacency entry = partner | type << 26 (| GD_ADJ_LOCAL)
@@ -32,15 +34,16 @@ enum { GD_FLAG_VIOLATION = 0, GD_FLAG_OVERFLOW = 1, GD_FLAG_MAXDISP2 = 2, GD_FLA
 
 // LDS tile of one block (tiled path): the block's 256 slots plus the slots of every cell adjacent
 // to its cells, as 9 contiguous slot ranges (one per (dz,dy) row offset of the cell grid).
-struct TileDesc {
+struct TileDesc {   // all fields 32-bit: the kernels read it through a block-uniform pointer with scalar (s_load) loads;
+                    // 16-bit fields would be fetched with per-lane vector loads and a full vmcnt wait each
     unsigned start[GD_TILE_RANGES];        // first slot of the range
-    unsigned short len[GD_TILE_RANGES];    // slots in the range
-    unsigned short base[GD_TILE_RANGES];   // LDS index of the range's first slot
+    unsigned len[GD_TILE_RANGES];          // slots in the range
+    unsigned base[GD_TILE_RANGES];         // LDS index of the range's first slot
     unsigned total;                        // beads staged
     unsigned nranges;                      // merged ranges in use
     // per (dz,dy) row offset k: first slot of cell c0+off_k-1 and its LDS index (0xffffffff: no such row)
     unsigned kstart[GD_TILE_RANGES];
-    unsigned short kbase[GD_TILE_RANGES];
+    unsigned kbase[GD_TILE_RANGES];
 };
 
 struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
