@@ -618,7 +618,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.chain = s->chain.p; b.nbr = (with_list && !tiled) ? s->nbr.p : nullptr; b.nbr16 = tiled ? s->nbr16.p : nullptr;
     b.meta = s->meta.p; b.perm = s->perm.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
-    b.flags = s->flags.p; b.lcount = s->lcount_d.p;
+    b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
     gd_launch_build(b, s->stream);
     s->list_tiled = tiled;
     s->pcur ^= 1; s->ocur ^= 1;
@@ -959,7 +959,7 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
     if (what >= 10) HIPCHK(hipMemsetAsync(s->fout.p, 0, s->fout.n * sizeof(float4), s->stream));
     HIPCHK(hipEventRecord(e0, s->stream));
     for (int i = 0; i < n; i++) {
-        if (what == 0) { GDCHK(enqueue_build(s, rv, pair_cutoff(s) > 0)); }
+        if (what == 0 || what >= 30) { GDCHK(enqueue_build(s, rv, pair_cutoff(s) > 0)); }
         else gd_launch_step(p, GD_MODE_STEP, s->stream);
     }
     HIPCHK(hipEventRecord(e1, s->stream));
@@ -975,8 +975,9 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
         std::vector<unsigned long long> rec(std::min<size_t>(s->fout.n * 2, (size_t)1 << 22));
         HIPCHK(hipMemcpy(rec.data(), s->fout.p, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double sum = 0, waves = 0;
+        const int idx = what >= 30 ? what - 30 : what - 10;
         for (size_t w = 0; w + 16 <= rec.size(); w += 16)
-            if (rec[w + 15] == 1ull && what - 10 < 12) { sum += (double)rec[w + what - 10]; waves += 1; }
+            if (rec[w + 15] == 1ull && idx >= 0 && idx < 12) { sum += (double)rec[w + idx]; waves += 1; }
         *mean_ms = waves > 0 ? sum / waves : 0.0;
     }
     GDCHK(clear_flags(s));

@@ -929,12 +929,19 @@ __global__ void k_tiles(const BuildParams p)
 
 // Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
 // TILED: candidates are read from the block's LDS tile and list entries are tile indices.
+#if GD_ABL == 34
+#define GD_FSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); facc_[k] += now_ - ftprev_; ftprev_ = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GD_FSTAMP(k) do { } while (0)
+#endif
 template <bool PERIODIC, bool TILED>
 __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
+#if GD_ABL == 34
+    unsigned long long ftprev_ = __builtin_amdgcn_s_memtime(), facc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
-    __shared__ __attribute__((aligned(16))) uint4 s_stage[GD_BLOCK];   // one 16-byte list chunk under construction per thread
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -945,13 +952,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     const TileDesc *__restrict__ tdp = p.tiles + (size_t)r * p.nblk + blk;
 #define s_td (*tdp)
     if (TILED && GD_ABL != 4) {
+        // LDS-DMA staging as in k_step: descriptor by scalar loads first, then all pieces back to back
+        unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
+#pragma unroll
+        for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = s_td.len[k]; tst[k] = s_td.start[k]; tbase[k] = s_td.base[k]; }
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
-            const unsigned len = s_td.len[k], st = s_td.start[k], base = s_td.base[k];
-            for (unsigned q = threadIdx.x; q < len; q += GD_BLOCK) s_tile[base + q] = rpos[st + q];
+            const unsigned len = tlen[k], st = tst[k], base = tbase[k];
+            for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
+                if (q0 + lane < len)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
+                                                     (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
+            }
         }
         __syncthreads();
     }
+    GD_FSTAMP(0);     // staging + barrier
     unsigned cnt = 0;
     if (slot < p.N) {
         unsigned listlen = 0;
@@ -984,6 +1000,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             };
             p.chain[g] = make_int4(conv(c.x), conv(c.y), conv(c.z), conv(c.w));
         }
+        GD_FSTAMP(1);     // bond / chain re-map
         if (p.nbr || p.nbr16) {
             const GridP gp = p.grid[r];
             const float4 xi = rpos[slot];
@@ -996,13 +1013,28 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             constexpr unsigned PER = TILED ? 8u : 4u;
             const unsigned NC = p.W / PER;
             uint4 *__restrict__ lst = (TILED ? (uint4 *)p.nbr16 : (uint4 *)p.nbr) + (size_t)(g >> 6) * NC * 64 + (g & 63);
-            // an entry is written into the thread's LDS slot; every PER-th entry the finished chunk
+            // the 16-byte chunk under construction lives in four registers (an LDS staging slot per thread would cost
+            // the 8 KB that separate two from three resident blocks per CU); every PER-th entry the finished chunk
             // goes out as one 16-byte global store (2-byte scattered global stores were 25% of the build)
+            unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            // A finished chunk is parked in p0..p3 and stored at the next flush point (the end of a row window), where
+            // the lanes of the wave store together: one store instruction per row instead of one per append iteration.
+            unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0, pend = 0;      // pend: chunk index + 1 of the parked chunk, 0 = none
+            auto flush = [&]() {
+                if (pend) { lst[(size_t)(pend - 1) * 64] = make_uint4(p0, p1, p2, p3); pend = 0; }
+            };
             auto push = [&](unsigned j) {
-                if (TILED) ((unsigned short *)&s_stage[threadIdx.x])[cnt % PER] = (unsigned short)j;
-                else ((unsigned *)&s_stage[threadIdx.x])[cnt % PER] = j;
+                if (TILED) {        // 128-bit shift register: eight 16-bit entries, the first one ends up lowest
+                    w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
+                    w2 = __builtin_amdgcn_alignbit(w3, w2, 16); w3 = __builtin_amdgcn_alignbit(j, w3, 16);
+                } else {
+                    w0 = w1; w1 = w2; w2 = w3; w3 = j;
+                }
                 cnt++;
-                if (cnt % PER == 0 && cnt <= p.W) lst[(size_t)(cnt / PER - 1) * 64] = s_stage[threadIdx.x];
+                if (cnt % PER == 0 && cnt <= p.W) {
+                    flush();                                   // (only if a second chunk fills before the next flush point)
+                    p0 = w0; p1 = w1; p2 = w2; p3 = w3; pend = cnt / PER;
+                }
             };
             if (TILED) {
                 const unsigned x_lo = (unsigned)max(cx - 1, 0), x_hi = (unsigned)min(cx + 1, gp.nc[0] - 1);
@@ -1016,6 +1048,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     const unsigned row = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0]);
                     rb[k] = cs[row + x_lo]; re[k] = cs[row + x_hi + 1];
                 }
+                GD_FSTAMP(2);     // row bounds
 #pragma unroll
                 for (int k = 0; k < GD_TILE_RANGES; k++) {
 #if GD_ABL >= 2 && GD_ABL <= 4
@@ -1023,34 +1056,41 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     continue;
 #endif
                     const unsigned b = rb[k], e = re[k];
-                    if (e <= b) continue;
-                    const unsigned lb = s_td.kbase[k] + (b - s_td.kstart[k]), le = lb + (e - b);
-                    const unsigned self_l = lb + (slot - b);       // == own tile index when the bead is in this row segment
-                    // branch-free distance tests into a per-lane bit mask, then one append per set bit:
-                    // the (divergent) append code runs max-popcount times per segment, not once per candidate
-                    for (unsigned j0 = lb; j0 < le; j0 += 32) {
-                        const unsigned n = min(32u, le - j0);
-                        unsigned m = 0;
-                        // no per-candidate bookkeeping: reads may run up to 3 slots past the window (slack is
-                        // allocated behind the tile); the window end and the bead itself are masked once
-                        for (unsigned u0 = 0; u0 < n; u0 += 4) {
-                            const float4 *cj = s_tile + j0 + u0;
+                    if (e > b) {
+                        const unsigned lb = s_td.kbase[k] + (b - s_td.kstart[k]), le = lb + (e - b);
+                        const unsigned self_l = lb + (slot - b);       // == own tile index when the bead is in this row segment
+                        // branch-free distance tests into a per-lane bit mask, then one append per set bit:
+                        // the (divergent) append code runs max-popcount times per segment, not once per candidate
+                        for (unsigned j0 = lb; j0 < le; j0 += 32) {
+                            const unsigned n = min(32u, le - j0);
+                            unsigned m = 0;
+                            // seven instructions per candidate: r2 - rv2 by three subtractions and three fmas, and
+                            // its sign bit shifted into the mask by one v_alignbit (candidate i of the n4 tested ends
+                            // up at bit n4-1-i).  Reads may run up to 3 slots past the window (slack is allocated
+                            // behind the tile); those bits are shifted out below, the bead itself is masked once.
+                            for (unsigned u0 = 0; u0 < n; u0 += 4) {
+                                const float4 *cj = s_tile + j0 + u0;
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const float4 xj = cj[u];
-                                const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                                m |= (dx * dx + dy * dy + dz * dz < rv2 ? 1u : 0u) << (u0 + u);
+                                for (int u = 0; u < 4; u++) {
+                                    const float4 xj = cj[u];
+                                    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                                    const float t = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, -rv2)));      // < 0 inside the list radius
+                                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);              // m = m << 1 | sign(t)
+                                }
                             }
-                        }
-                        if (n < 32u) m &= (1u << n) - 1u;
-                        const unsigned sd = self_l - j0;
-                        if (sd < 32u) m &= ~(1u << sd);
-                        while (m) {
-                            const unsigned bit = __ffs(m) - 1;
-                            m &= m - 1;
-                            push(j0 + bit);
+                            m >>= ((n + 3u) & ~3u) - n;                      // candidate i now at bit n-1-i
+                            const unsigned sd = self_l - j0;
+                            if (sd < n) m &= ~(1u << (n - 1u - sd));
+                            GD_FSTAMP(3);     // distance tests
+                            while (m) {                                      // ascending candidate order
+                                const unsigned bit = 31u - (unsigned)__clz(m);
+                                m ^= 1u << bit;
+                                push(j0 + (n - 1u - bit));
+                            }
+                            GD_FSTAMP(4);     // appends
                         }
                     }
+                    flush();
                 }
             } else {
                 // distinct neighbour cells per dimension (small periodic grids alias)
@@ -1089,10 +1129,12 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             unsigned self = slot;
             if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = idx; }
             while (cnt % GD_UNROLL) push(self);
+            flush();
             cnt = found;
         }
         p.meta[g] = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
     }
+    GD_FSTAMP(5);     // padding, meta
     // block-local counting sort of the beads by list batches (longest first) -> perm for k_step
     {
         __shared__ unsigned s_hist[32], s_off[32];
@@ -1115,6 +1157,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         for (int w = 0; w < GD_BLOCK / 64; w++) t += s_cnt[w];
         if (t) atomicAdd(&p.lcount[r], t);
     }
+    GD_FSTAMP(6);     // perm + count
+#if GD_ABL == 34
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long *rec = p.dbg + ((size_t)blockIdx.x * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 16;
+        for (int k = 0; k < 12; k++) rec[k] = facc_[k];
+        rec[15] = 1ull;
+    }
+#endif
 }
 
 #undef s_td

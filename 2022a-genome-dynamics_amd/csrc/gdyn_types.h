@@ -196,6 +196,7 @@ struct BuildParams {
     unsigned cpb, tile_cap;
     unsigned *flags;
     unsigned long long *lcount;         // [R] directed list entries
+    unsigned long long *dbg;            // section stamps of timing-only builds (the force-output buffer)
 };
 
 // launchers (gdyn_kernels.hip)

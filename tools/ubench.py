@@ -22,3 +22,7 @@ if os.environ.get("GDYN_STAMPS"):
     names = ["ctx/tail-of-prologue", "barrier", "pairs", "bonds", "bend+ps", "wall", "integrate", "perm", "dma-issue", "oid", "noise", "bead-loads-issue"]
     vals = [s.debug_bench(10 + k, 20) for k in range(12)]
     print("   cycles/wave: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
+if os.environ.get("GDYN_FSTAMPS"):
+    names = ["stage+barrier", "remap", "rowbounds", "tests", "appends", "pad+meta", "perm+count"]
+    vals = [s.debug_bench(30 + k, 10) for k in range(7)]
+    print("   k_fill cycles/wave: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
