@@ -94,6 +94,7 @@ struct gd_system {
     int pcur = 0, ccur = 0;
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
+    uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
     uint32_t cpb = 1, tile_cap = 3280;
 
     // tuning / cadence
@@ -555,7 +556,7 @@ static void fill_common(gd_system *s, StepParams &p)
     p.pos_in = s->pos[s->pcur].p; p.pos_out = s->pos[s->pcur ^ 1].p; p.xb = s->xb.p; p.orig = s->orig[s->ocur].p;
     p.ab = s->ab.p; p.mob = s->mobs.p; p.bendE = s->bendE.p; p.mob_uniform = s->mob_uniform; p.WB = s->WB;
     p.nbr = s->nbr.p; p.nbr16 = s->nbr16.p; p.tiles = s->tiles.p; p.tiled = s->list_tiled ? 1 : 0; p.packed_ab = s->packed_ab ? 1 : 0;
-    p.cpb = s->cpb; p.tile_cap = s->tile_cap;
+    p.cpb = s->cpb; p.tile_cap = s->list_tiled ? s->list_tile_cap : s->tile_cap;   // as at the build of the list in use
     p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
     p.meta = s->meta.p; p.perm = s->perm.p; p.W = s->W; p.badj = s->badj.p; p.chain = s->chain.p;
     p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.react_part = s->react_part.p; p.flags = s->flags.p;
@@ -620,7 +621,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
     gd_launch_build(b, s->stream);
-    s->list_tiled = tiled;
+    s->list_tiled = tiled; s->list_tile_cap = s->tile_cap;
     s->pcur ^= 1; s->ocur ^= 1;
     s->rv = rv; s->steps_since_build = 0; s->rebuilds++;
     s->timing.rebuild_launches++;

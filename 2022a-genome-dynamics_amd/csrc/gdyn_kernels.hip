@@ -68,9 +68,10 @@ __device__ __forceinline__ float pack_ab(float2 ab)
 // waca = wa*ca and wbcb = wb*cb come in pre-multiplied (one fma each from the neighbour's a/b).
 __device__ __forceinline__ float softcore_2383(float r2, float inv_sa2, float inv_sb2, float waca, float wbcb)
 {
-    const float ga = fmaxf(fmaf(-r2, inv_sa2, 1.0f), 0.0f);
+    // both arguments are <= 1, so max(., 0) is the [0,1] clamp -- which is free as the output modifier of the fma
+    const float ga = __builtin_amdgcn_fmed3f(fmaf(-r2, inv_sa2, 1.0f), 0.0f, 1.0f);
     const float u2 = r2 * inv_sb2, u4 = u2 * u2;
-    const float gb = fmaxf(fmaf(-u4, u4, 1.0f), 0.0f);
+    const float gb = __builtin_amdgcn_fmed3f(fmaf(-u4, u4, 1.0f), 0.0f, 1.0f);
     return fmaf(wbcb * (gb * gb), u4 * u2, waca * (ga * ga));
 }
 __device__ __forceinline__ float softcore_2383_energy(float r2, float inv_sa2, float inv_sb2, float ea, float eb, float wa, float wb)
@@ -242,7 +243,9 @@ struct CtxF {
 // cells, 9 contiguous slot ranges, TileDesc) with coalesced loads; pair-list entries are 16-bit
 // indices into that tile, so the neighbour gather is an LDS read.  PK=1/2: softcore<2,3>+<8,3>
 // with / without AB mixing (compile-time), PK=0: runtime powers.
-template <int MODE, bool PERIODIC, bool TILED, int PK>
+// S16 (tiled lists only): entries are BYTE offsets into the tile (tile capacity < 4096 entries), one decode
+// instruction per entry instead of mask + shift-add
+template <int MODE, bool PERIODIC, bool TILED, int PK, bool S16>
 __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                 for (int u = 0; u < GD_UNROLL; u++) {
                     if (GD_ABL == 22) xjv[u] = s_tile[(threadIdx.x + 64u * u + k0) & 2047u];          // conflict-free LDS reads
                     else if (GD_ABL == 23) xjv[u] = make_float4(xi.x + 0.01f * (float)(jj[u] & 15u), xi.y + 0.02f, xi.z, xi4.w);   // no LDS
-                    else xjv[u] = TILED ? s_tile[jj[u]] : rpos[jj[u]];
+                    else xjv[u] = !TILED ? rpos[jj[u]] : S16 ? *(const float4 *)((const char *)s_tile + jj[u]) : s_tile[jj[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < GD_UNROLL; u++) {
@@ -666,15 +669,20 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
         static bool once = false;
         if (!once) {
             once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
     }
-#define L(PER, TIL, PK) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK>), grid, block, lds, st, p)
-    if (p.periodic) { if (p.pk == 1) L(true, false, 1); else if (p.pk == 2) L(true, false, 2); else L(true, false, 0); }
-    else if (p.tiled) { if (p.pk == 1) L(false, true, 1); else if (p.pk == 2) L(false, true, 2); else L(false, true, 0); }
-    else { if (p.pk == 1) L(false, false, 1); else if (p.pk == 2) L(false, false, 2); else L(false, false, 0); }
+#define L(PER, TIL, PK, S) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK, S>), grid, block, lds, st, p)
+    const bool s16 = p.tiled && p.tile_cap < 4096u;      // must match k_fill's choice (gd_launch_build)
+    if (p.periodic) { if (p.pk == 1) L(true, false, 1, false); else if (p.pk == 2) L(true, false, 2, false); else L(true, false, 0, false); }
+    else if (p.tiled && s16) { if (p.pk == 1) L(false, true, 1, true); else if (p.pk == 2) L(false, true, 2, true); else L(false, true, 0, true); }
+    else if (p.tiled) { if (p.pk == 1) L(false, true, 1, false); else if (p.pk == 2) L(false, true, 2, false); else L(false, true, 0, false); }
+    else { if (p.pk == 1) L(false, false, 1, false); else if (p.pk == 2) L(false, false, 2, false); else L(false, false, 0, false); }
 #undef L
 }
 
@@ -934,7 +942,7 @@ __global__ void k_tiles(const BuildParams p)
 #else
 #define GD_FSTAMP(k) do { } while (0)
 #endif
-template <bool PERIODIC, bool TILED>
+template <bool PERIODIC, bool TILED, bool S16>
 __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
 #if GD_ABL == 34
@@ -1085,7 +1093,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             while (m) {                                      // ascending candidate order
                                 const unsigned bit = 31u - (unsigned)__clz(m);
                                 m ^= 1u << bit;
-                                push(j0 + (n - 1u - bit));
+                                push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
                             }
                             GD_FSTAMP(4);     // appends
                         }
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             listlen = min(found, p.W);
             // pad to a multiple of GD_UNROLL (W is one) with the bead itself: zero displacement, zero force
             unsigned self = slot;
-            if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = idx; }
+            if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = S16 ? idx << 4 : idx; }
             while (cnt % GD_UNROLL) push(self);
             flush();
             cnt = found;
@@ -1184,12 +1192,15 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
         static bool once = false;
         if (!once) {
             once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
         hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
-        hipLaunchKernelGGL((k_fill<false, true>), gridx, block, (size_t)(p.tile_cap + 4) * sizeof(float4), st, p);   // +4: read slack
-    } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false>), gridx, block, 0, st, p);
-    else hipLaunchKernelGGL((k_fill<false, false>), gridx, block, 0, st, p);
+        const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
+        if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<false, true, true>), gridx, block, lds, st, p);    // byte-offset entries, as k_step expects
+        else hipLaunchKernelGGL((k_fill<false, true, false>), gridx, block, lds, st, p);
+    } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false, false>), gridx, block, 0, st, p);
+    else hipLaunchKernelGGL((k_fill<false, false, false>), gridx, block, 0, st, p);
 }
 
 // ------------------------------------------------------------------- misc
