@@ -267,6 +267,10 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 #if GD_ABL == 30
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime(), acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // replica context: the two scalars every wave needs (noise counter) are fetched here, before any DMA, so that they
+    // stay scalar loads; wave 0 also starts its full-context and reaction-partial loads first
+    const long long ctx_step0 = p.ctx_in[r].step;
+    const int ctx_pending0 = p.ctx_in[r].pending;
     // ---- prologue, ordered for the in-order vmcnt counter: first everything that does not depend on the thread->bead
     // permutation (bond table and tile go straight into LDS by DMA, nothing returns to registers), then the perm load
     // and the per-bead loads; the noise then waits for the youngest loads only (a static vmcnt).
@@ -323,22 +327,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     asm volatile("" :: "v"(oid));
     GD_STAMP(9);      // oid arrived
 #endif
-    // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
-    // and the per-bead loads are in flight (the step index comes from a uniform scalar load)
-    float3 z = make_float3(0.f, 0.f, 0.f);
-    if (MODE == GD_MODE_STEP && GD_ABL != 14 && valid && p.kT > 0.f) {
-        if (p.noise_mode == NOISE_PHILOX) {
-            const long long step_now = p.ctx_in[r].step + (p.ctx_in[r].pending ? 1 : 0);
-            z = philox_normal3(p.seed, oid, step_now + 1, r);
-        } else if (p.noise_mode == NOISE_HOST) {
-            const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
-            z = make_float3(h[0], h[1], h[2]);
-        }
-    }
-#if GD_ABL == 30
-    asm volatile("" :: "v"(z.x), "v"(z.y), "v"(z.z));
-    GD_STAMP(10);     // noise
-#endif
+    // wave 0: pending callback + float copy of the context for the block (its loads overlap the bead loads above)
     if (wid == 0) {
         DevCtx c = p.ctx_in[r];
         if (MODE == GD_MODE_STEP) {
@@ -351,6 +340,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             s_ctx.step = c.step;
         }
     }
+    // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
+    // and the per-bead loads are in flight (the step index comes from a uniform scalar load)
+    float3 z = make_float3(0.f, 0.f, 0.f);
+    if (MODE == GD_MODE_STEP && GD_ABL != 14 && valid && p.kT > 0.f) {
+        if (p.noise_mode == NOISE_PHILOX) {
+            const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
+            z = philox_normal3(p.seed, oid, step_now + 1, r);
+        } else if (p.noise_mode == NOISE_HOST) {
+            const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
+            z = make_float3(h[0], h[1], h[2]);
+        }
+    }
+#if GD_ABL == 30
+    asm volatile("" :: "v"(z.x), "v"(z.y), "v"(z.z));
+    GD_STAMP(10);     // noise
+#endif
     GD_STAMP(0);      // prologue: loads issued, tile DMA issued, noise
     __syncthreads();
     GD_STAMP(1);      // barrier (tile arrival)
@@ -931,6 +936,7 @@ __global__ void k_tiles(const BuildParams p)
     }
     td.nranges = truncated ? 0u : (unsigned)nm;
     td.total = total;
+
     atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
     p.tiles[t] = td;
 }
@@ -958,12 +964,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     // block-uniform descriptor, read through a uniform pointer (scalar loads; a local copy indexed in
     // loops would be demoted to scratch memory)
     const TileDesc *__restrict__ tdp = p.tiles + (size_t)r * p.nblk + blk;
-#define s_td (*tdp)
+    // The descriptor is read many times, also after this thread has stored list chunks: from global memory those
+    // reads become per-lane vector loads behind a full vmcnt(0) wait (the compiler cannot keep them scalar after a
+    // store), so it is copied once into LDS (188 bytes) and read from there.
+    __shared__ TileDesc s_tdesc;
+#define s_td s_tdesc
     if (TILED && GD_ABL != 4) {
         // LDS-DMA staging as in k_step: descriptor by scalar loads first, then all pieces back to back
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
 #pragma unroll
-        for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = s_td.len[k]; tst[k] = s_td.start[k]; tbase[k] = s_td.base[k]; }
+        for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = tdp->len[k]; tst[k] = tdp->start[k]; tbase[k] = tdp->base[k]; }
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
             const unsigned len = tlen[k], st = tst[k], base = tbase[k];
@@ -973,6 +983,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                                                      (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
             }
         }
+    }
+    if (TILED) {       // (after the DMA issue in program order: the copy's wait then coincides with the barrier's)
+        if (threadIdx.x < sizeof(TileDesc) / 4) ((unsigned *)&s_tdesc)[threadIdx.x] = ((const unsigned *)tdp)[threadIdx.x];
         __syncthreads();
     }
     GD_FSTAMP(0);     // staging + barrier
@@ -990,12 +1003,23 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             return false;
         };
         const unsigned deg = (GD_ABL == 3 || GD_ABL == 4) ? 0u : p.bdeg_o[o];
-        unsigned *__restrict__ adjw = (unsigned *)((uint4 *)p.badj + (size_t)(g >> 6) * (p.WB / 4) * 64 + (g & 63));
-        for (unsigned k = 0; k < deg; k++) {
-            const unsigned ent = p.badj_o[(size_t)k * p.N + o];
-            unsigned ps = so[ent & GD_ADJ_MASK], idx, out = ps | (ent & ~GD_ADJ_MASK);
-            if (TILED && to_local(ps, idx)) out = idx | (ent & ~GD_ADJ_MASK) | GD_ADJ_LOCAL;
-            adjw[(size_t)(k >> 2) * 64 * 4 + (k & 3u)] = out;
+        uint4 *__restrict__ adjw = (uint4 *)p.badj + (size_t)(g >> 6) * (p.WB / 4) * 64 + (g & 63);
+        // one 16-byte adjacency chunk per round: its four gathers (entry by bead, then slot by partner) are in flight
+        // together and the chunk is written with one store
+        for (unsigned k0 = 0; k0 < deg; k0 += 4) {
+            unsigned ent[4], ps[4], out[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) ent[u] = k0 + u < deg ? p.badj_o[(size_t)(k0 + u) * p.N + o] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) ps[u] = k0 + u < deg ? so[ent[u] & GD_ADJ_MASK] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                unsigned idx;
+                out[u] = ps[u] | (ent[u] & ~GD_ADJ_MASK);
+                if (TILED && to_local(ps[u], idx)) out[u] = idx | (ent[u] & ~GD_ADJ_MASK) | GD_ADJ_LOCAL;
+                if (k0 + u >= deg) out[u] = 0u;
+            }
+            adjw[(size_t)(k0 >> 2) * 64] = make_uint4(out[0], out[1], out[2], out[3]);
         }
         if (p.chain_o) {
             const int4 c = p.chain_o[o];
