@@ -98,7 +98,7 @@ struct gd_system {
     uint32_t cpb = 1, tile_cap = 3280;
 
     // tuning / cadence
-    double skin = 0.8;
+    double skin = 0.75;   // relative to the pair cutoff; 0.65..0.8 are within 3% of each other on S-genome-30k, smaller tiles leave more LDS margin
     uint32_t K = 4, adapt = 1, use_graph = 0;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
