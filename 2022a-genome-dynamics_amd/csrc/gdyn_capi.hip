@@ -151,6 +151,7 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     s->nblk = (s->N + GD_BLOCK - 1) / GD_BLOCK;
     s->Np = s->nblk * GD_BLOCK;
     s->cpb = (s->nblk + GD_XCDS - 1) / GD_XCDS;
+    if (s->R % GD_XCDS == 0 && !getenv("GDYN_SLICE_MAP")) s->cpb = 0;      // whole replicas per XCD (see block_map)
     s->a.assign(s->N, 0.0); s->b.assign(s->N, 0.0); s->mob.assign(s->N, 1.0); s->bend.assign(s->N, 0.0);
     s->hctx.assign(s->R, DevCtx{});
     for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; }   // wall_semiaxes {0,0,0} until a wall is set (simulation_context.hpp:16)

@@ -43,9 +43,12 @@
 // physical block b runs on XCD b%8.  Every XCD gets one contiguous chunk (cpb blocks = a slab
 // of cell-sorted slots) of every replica, so the halo re-reads of neighbouring blocks hit that
 // XCD's L2.  Speed only: any placement gives the same results.
+// cpb == 0 (replica count a multiple of 8): whole replicas per XCD instead -- XCD x runs replicas x, x+8, ... block by
+// block, so no tile halo is shared between XCDs at all.
 __device__ __forceinline__ bool block_map(unsigned b, unsigned nblk, unsigned cpb, unsigned &r, unsigned &blk)
 {
     const unsigned xcd = b % GD_XCDS, q = b / GD_XCDS;
+    if (cpb == 0) { r = (q / nblk) * GD_XCDS + xcd; blk = q % nblk; return true; }
     r = q / cpb;
     blk = xcd * cpb + q % cpb;
     return blk < nblk;
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(64) void k_finalize(const StepParams p, int reduce_
 template <int MODE>
 static void launch_step_mode(const StepParams &p, hipStream_t st)
 {
-    const dim3 grid(GD_XCDS * p.cpb * p.R), block(GD_BLOCK);
+    const dim3 grid(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk), block(GD_BLOCK);
     const size_t lds = p.tiled ? (size_t)p.tile_cap * sizeof(float4) : 0;
     if (p.tiled) {   // opt in to more than 64 KB of LDS per block (gfx950: 160 KB per CU)
         static bool once = false;
@@ -1203,7 +1206,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 
 void gd_launch_build(const BuildParams &p, hipStream_t st)
 {
-    const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(GD_XCDS * p.cpb * p.R);
+    const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk);
     hipLaunchKernelGGL(k_build_init, dim3((p.R + 63) / 64), dim3(64), 0, st, p);
     if (!p.periodic) hipLaunchKernelGGL(k_bbox, grid, block, 0, st, p);
     hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(64), 0, st, p);
