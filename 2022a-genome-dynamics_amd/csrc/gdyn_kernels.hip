@@ -54,6 +54,13 @@ __device__ __forceinline__ bool block_map(unsigned b, unsigned nblk, unsigned cp
     return blk < nblk;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load(const uint4 *ptr)      // streaming 16-byte load (non-temporal hint)
+{
+    const u32x4 v = __builtin_nontemporal_load((const u32x4 *)ptr);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float2 unpack_ab(float w)
 {
     const unsigned u = __float_as_uint(w);
@@ -323,7 +330,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         if (MODE != GD_MODE_ENERGY) oid = p.orig[g];
         if (MODE == GD_MODE_STEP) { x0 = p.xb[g]; if (p.mob_uniform < 0.f) mu = p.mob[g]; }
         if (p.has_bonds) adj0 = adj[0];
-        if (p.pair.enabled) { qa = lst[0]; if (!TILED) qb = lst[64]; }
+        // list chunks are read once per step and never reused: non-temporal, so they do not displace the tiles'
+        // halo lines (which neighbouring blocks re-read) from the XCD's L2
+        if (p.pair.enabled) { qa = nt_load(&lst[0]); if (!TILED) qb = lst[64]; }
     }
     GD_STAMP(8);      // bead loads, bond table, tile DMA issued
 #if GD_ABL == 30
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                 float4 xjv[GD_UNROLL];
                 const uint4 q = qa, q0 = qa, q1 = qb;
                 if (k0 + GD_UNROLL < cntp) {
-                    if (TILED) qa = lst[(size_t)(k0 / 8 + 1) * 64];
+                    if (TILED) qa = nt_load(&lst[(size_t)(k0 / 8 + 1) * 64]);
                     else { qa = lst[(size_t)(k0 / 4 + 2) * 64]; qb = lst[(size_t)(k0 / 4 + 3) * 64]; }
                 }
                 if (TILED) {
@@ -1056,7 +1065,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // the lanes of the wave store together: one store instruction per row instead of one per append iteration.
             unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0, pend = 0;      // pend: chunk index + 1 of the parked chunk, 0 = none
             auto flush = [&]() {
-                if (pend) { lst[(size_t)(pend - 1) * 64] = make_uint4(p0, p1, p2, p3); pend = 0; }
+                if (pend) { lst[(size_t)(pend - 1) * 64] = make_uint4(p0, p1, p2, p3); pend = 0; }      // (non-temporal stores here cost 15%: the partial lines no longer merge in L2)
             };
             auto push = [&](unsigned j) {
                 if (TILED) {        // 128-bit shift register: eight 16-bit entries, the first one ends up lowest
