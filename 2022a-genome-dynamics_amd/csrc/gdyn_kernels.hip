@@ -1113,6 +1113,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             // up at bit n4-1-i).  Reads may run up to 3 slots past the window (slack is allocated
                             // behind the tile); those bits are shifted out below, the bead itself is masked once.
                             for (unsigned u0 = 0; u0 < n; u0 += 4) {
+#if GD_ABL == 34
+                                facc_[8] += 1;        // wave-level test groups (lane 0 runs while any lane does)
+#endif
                                 const float4 *cj = s_tile + j0 + u0;
 #pragma unroll
                                 for (int u = 0; u < 4; u++) {
@@ -1127,6 +1130,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             if (sd < n) m &= ~(1u << (n - 1u - sd));
                             GD_FSTAMP(3);     // distance tests
                             while (m) {                                      // ascending candidate order
+#if GD_ABL == 34
+                                facc_[9] += 1;
+#endif
                                 const unsigned bit = 31u - (unsigned)__clz(m);
                                 m ^= 1u << bit;
                                 push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));

@@ -68,12 +68,13 @@ def test_injected_noise_trajectory(hip, name):
     assert np.abs(s.positions() - GOLD[f"{name}/x_host5"]).max() <= POS_ATOL_20STEP * scale
 
 
-@pytest.mark.parametrize("name", ["genome", "chromatin_1kb"])
-def test_replica_batch_matches_oracle(hip, oracle, name):
-    """R replicas in one launch: each replica is its own trajectory with its own Philox stream and context."""
+@pytest.mark.parametrize("name,nrep", [("genome", 3), ("chromatin_1kb", 3), ("genome", 8)])
+def test_replica_batch_matches_oracle(hip, oracle, name, nrep):
+    """R replicas in one launch: each replica is its own trajectory with its own Philox stream and context.
+    (3 replicas: every XCD runs a slice of each replica; 8: whole replicas per XCD -- the block maps of block_map().)"""
     _, _, dt, kT, flags = CASES[name]
-    sh, *_ = build(hip, name, n_replicas=3)
-    so, *_ = build(oracle, name, n_replicas=3)
+    sh, *_ = build(hip, name, n_replicas=nrep)
+    so, *_ = build(oracle, name, n_replicas=nrep)
     x0 = so.positions()
     x0[1] += 0.01 * np.random.default_rng(1).normal(size=x0[1].shape)     # make the replicas differ
     for s in (sh, so):
@@ -86,7 +87,7 @@ def test_replica_batch_matches_oracle(hip, oracle, name):
     xh, xo = sh.positions(), so.positions()
     assert np.abs(xh - xo).max() <= POS_ATOL_20STEP * max(1.0, np.abs(xo).max() / 8)
     assert np.abs(xo[0] - xo[2]).max() > 1e-4            # same start, different replica index => different noise
-    for r in range(3):
+    for r in range(nrep):
         assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), atol=1e-8)
 
 

@@ -25,4 +25,5 @@ if os.environ.get("GDYN_STAMPS"):
 if os.environ.get("GDYN_FSTAMPS"):
     names = ["stage+barrier", "remap", "rowbounds", "tests", "appends", "pad+meta", "perm+count"]
     vals = [s.debug_bench(30 + k, 10) for k in range(7)]
+    print("   lane-0 test groups per wave %.1f, append iterations %.1f" % (s.debug_bench(38, 10) / 10, s.debug_bench(39, 10) / 10))
     print("   k_fill cycles/wave: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
