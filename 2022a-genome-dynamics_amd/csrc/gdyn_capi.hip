@@ -94,6 +94,7 @@ struct gd_system {
     int pcur = 0, ccur = 0;
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
+    uint32_t tile_hold = 0;        // chunks to stay in the larger tile class after an overflow
     uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
     uint32_t cpb = 1, tile_cap = 3280;
 
@@ -667,7 +668,10 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // size the LDS tile to what the builds actually need (more resident blocks per CU)
         // LDS capacity is a step function of the tile size: k_step keeps 3 / 2 / 1 blocks (6 / 4 / 2 waves per SIMD)
         // resident per CU up to these tile capacities, so the capacity is always the largest one of its occupancy class
-        const unsigned want = pick_tile_cap(need_t + need_t / 50 + 16);
+        // (the tiles of consecutive builds differ by a few entries; an overflow costs one rolled-back chunk and then
+        // keeps the larger class for a while, so the margin for the smaller class can be thin)
+        unsigned want = pick_tile_cap(need_t + 24);
+        if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
         if (want != s->tile_cap && want <= 8192u) {
             if (getenv("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
@@ -675,7 +679,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     }
     if (tover) {
         const unsigned cap = pick_tile_cap(need_t + need_t / 16 + 32);
-        if (cap <= 8192) s->tile_cap = cap;    // 128 KB dynamic + static part < 160 KB of LDS per CU
+        if (cap <= 8192) { s->tile_cap = cap; s->tile_hold = 4; }    // 128 KB dynamic + static part < 160 KB of LDS per CU
         else s->tiled_ok = false;                // too dense for one tile: generic path
     }
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
