@@ -591,7 +591,7 @@ static void fill_common(gd_system *s, StepParams &p)
 // Enqueue one list build (counting sort into slot order + ELL fill) with radius rv.
 static bool want_tiled(const gd_system *s)
 {
-    return s->kernel_path != 1 && s->tiled_ok && s->box_kind == GD_BOX_OPEN && s->packed_ab;
+    return s->kernel_path != 1 && s->tiled_ok && s->packed_ab;      // open and periodic boxes alike
 }
 
 static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tiled = true)
@@ -679,7 +679,10 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     }
     if (tover) {
         const unsigned cap = pick_tile_cap(need_t + need_t / 16 + 32);
-        if (cap <= 8192) { s->tile_cap = cap; s->tile_hold = 4; }    // 128 KB dynamic + static part < 160 KB of LDS per CU
+        // 128 KB dynamic + static part < 160 KB of LDS per CU.  Periodic tiles are whole rows of cells and pay the minimum
+        // image per pair: with one resident block per CU they lose to the generic path (measured on S-1kb-250k)
+        const unsigned cap_max = s->box_kind == GD_BOX_PERIODIC ? 5040u : 8192u;
+        if (cap <= cap_max) { s->tile_cap = cap; s->tile_hold = 4; }
         else s->tiled_ok = false;                // too dense for one tile: generic path
     }
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);

@@ -689,6 +689,12 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -696,7 +702,9 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
     }
 #define L(PER, TIL, PK, S) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK, S>), grid, block, lds, st, p)
     const bool s16 = p.tiled && p.tile_cap < 4096u;      // must match k_fill's choice (gd_launch_build)
-    if (p.periodic) { if (p.pk == 1) L(true, false, 1, false); else if (p.pk == 2) L(true, false, 2, false); else L(true, false, 0, false); }
+    if (p.periodic && p.tiled && s16) { if (p.pk == 1) L(true, true, 1, true); else if (p.pk == 2) L(true, true, 2, true); else L(true, true, 0, true); }
+    else if (p.periodic && p.tiled) { if (p.pk == 1) L(true, true, 1, false); else if (p.pk == 2) L(true, true, 2, false); else L(true, true, 0, false); }
+    else if (p.periodic) { if (p.pk == 1) L(true, false, 1, false); else if (p.pk == 2) L(true, false, 2, false); else L(true, false, 0, false); }
     else if (p.tiled && s16) { if (p.pk == 1) L(false, true, 1, true); else if (p.pk == 2) L(false, true, 2, true); else L(false, true, 0, true); }
     else if (p.tiled) { if (p.pk == 1) L(false, true, 1, false); else if (p.pk == 2) L(false, true, 2, false); else L(false, true, 0, false); }
     else { if (p.pk == 1) L(false, false, 1, false); else if (p.pk == 2) L(false, false, 2, false); else L(false, false, 0, false); }
@@ -914,6 +922,51 @@ __global__ void k_tiles(const BuildParams p)
     const unsigned first = blk * GD_BLOCK, last = min(first + GD_BLOCK, p.N) - 1;
     const int c0 = (int)p.cell_s[rbase + first], c1 = (int)p.cell_s[rbase + last];
     TileDesc td;
+    if (p.periodic) {
+        // Periodic boxes: the tile is made of WHOLE rows of cells (a row = fixed (z,y), all x; the x-neighbours of the
+        // first and last cell of a row are in the same row).  Rows needed = the 3 x 3 (dz,dy) neighbours, wrapped, of
+        // every row the block touches; consecutive rows are contiguous in slot order and merge into one range.
+        const int nx = gp.nc[0], ny = gp.nc[1], nz = gp.nc[2], nrows = ny * nz;
+        const int r0 = c0 / nx, r1 = c1 / nx;
+        unsigned bits[64];                               // row bitmap (<= 2048 rows; larger grids take the generic path)
+        bool ok = nrows <= 2048 && nx >= 3 && ny >= 3 && nz >= 3;
+        for (int i = 0; i < 64; i++) bits[i] = 0;
+        for (int rw = r0; ok && rw <= r1; rw++) {
+            const int z = rw / ny, y = rw % ny;
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int q = ((z + dz + nz) % nz) * ny + (y + dy + ny) % ny;
+                    bits[q >> 5] |= 1u << (q & 31);
+                }
+        }
+        unsigned total = 0; int nm = 0; bool truncated = !ok;
+        for (int k = 0; k < GD_TILE_RANGES; k++) { td.start[k] = 0; td.len[k] = 0; td.base[k] = 0; td.kstart[k] = 0xffffffffu; td.kbase[k] = 0; }
+        if (!ok) {      // grid too small (aliasing neighbours) or too large for the row bitmap: generic path
+            p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
+            atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], 1u << 20);
+        }
+        for (int q = 0; ok && q < nrows; ) {
+            if (!((bits[q >> 5] >> (q & 31)) & 1u)) { q++; continue; }
+            int e = q;
+            while (e + 1 < nrows && ((bits[(e + 1) >> 5] >> ((e + 1) & 31)) & 1u)) e++;
+            const unsigned st = cs[q * nx], len = cs[(e + 1) * nx] - st;
+            if (nm >= GD_TILE_RANGES || total + len > p.tile_cap) {
+                p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
+                // too many ranges cannot be cured by a larger tile: report a need beyond every capacity
+                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], nm >= GD_TILE_RANGES ? 1u << 20 : total + len);
+                truncated = true;
+                break;
+            }
+            td.start[nm] = st; td.len[nm] = len; td.base[nm] = total;
+            total += len; nm++;
+            q = e + 1;
+        }
+        td.nranges = truncated ? 0u : (unsigned)nm;
+        td.total = total;
+        atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
+        p.tiles[t] = td;
+        return;
+    }
     // the 9 (dz,dy) cell ranges come out ordered by their first cell; merge the overlapping ones
     int mlo[GD_TILE_RANGES], mhi[GD_TILE_RANGES], klo[GD_TILE_RANGES], kin[GD_TILE_RANGES], nm = 0;
     for (int k = 0; k < GD_TILE_RANGES; k++) {
@@ -1080,7 +1133,53 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     p0 = w0; p1 = w1; p2 = w2; p3 = w3; pend = cnt / PER;
                 }
             };
-            if (TILED) {
+            if (TILED && PERIODIC) {
+                // periodic tile = whole rows: for each of the 9 wrapped (dz,dy) rows the x-window cx-1..cx+1 is one
+                // slot interval, or two when it wraps around the row end; candidates are compared under the minimum image
+                const int nx = gp.nc[0], ny = gp.nc[1], nz = gp.nc[2];
+                unsigned pb[2 * GD_TILE_RANGES], pe[2 * GD_TILE_RANGES];
+#pragma unroll
+                for (int k = 0; k < GD_TILE_RANGES; k++) {
+                    const int zz = (cz + k / 3 - 1 + nz) % nz, yy = (cy + k % 3 - 1 + ny) % ny;
+                    const unsigned row = (unsigned)((zz * ny + yy) * nx);
+                    if (cx == 0) { pb[2 * k] = cs[row]; pe[2 * k] = cs[row + 2]; pb[2 * k + 1] = cs[row + nx - 1]; pe[2 * k + 1] = cs[row + nx]; }
+                    else if (cx == nx - 1) { pb[2 * k] = cs[row]; pe[2 * k] = cs[row + 1]; pb[2 * k + 1] = cs[row + nx - 2]; pe[2 * k + 1] = cs[row + nx]; }
+                    else { pb[2 * k] = cs[row + cx - 1]; pe[2 * k] = cs[row + cx + 2]; pb[2 * k + 1] = 0; pe[2 * k + 1] = 0; }
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 2 * GD_TILE_RANGES; k2++) {
+                    const unsigned b = pb[k2], e = pe[k2];
+                    if (e > b) {
+                        unsigned lb = 0;
+                        if (!to_local(b, lb)) { p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u; continue; }   // (cannot happen: the row is staged)
+                        const unsigned le = lb + (e - b);
+                        const unsigned self_l = lb + (slot - b);
+                        for (unsigned j0 = lb; j0 < le; j0 += 32) {
+                            const unsigned n = min(32u, le - j0);
+                            unsigned m = 0;
+                            for (unsigned u0 = 0; u0 < n; u0 += 4) {
+                                const float4 *cj = s_tile + j0 + u0;
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const float4 xj = cj[u];
+                                    const float3 d = min_image(make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z), p.box, p.inv_box);
+                                    const float t = fmaf(d.z, d.z, fmaf(d.y, d.y, fmaf(d.x, d.x, -rv2)));
+                                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);
+                                }
+                            }
+                            m >>= ((n + 3u) & ~3u) - n;
+                            const unsigned sd = self_l - j0;
+                            if (sd < n) m &= ~(1u << (n - 1u - sd));
+                            while (m) {
+                                const unsigned bit = 31u - (unsigned)__clz(m);
+                                m ^= 1u << bit;
+                                push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
+                            }
+                        }
+                    }
+                    if (k2 & 1) flush();
+                }
+            } else if (TILED) {
                 const unsigned x_lo = (unsigned)max(cx - 1, 0), x_hi = (unsigned)min(cx + 1, gp.nc[0] - 1);
                 // all 18 row-bound loads are issued before the first sweep (memory-level parallelism)
                 unsigned rb[GD_TILE_RANGES], re[GD_TILE_RANGES];
@@ -1236,10 +1335,15 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
             once = true;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
         hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
         const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
-        if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<false, true, true>), gridx, block, lds, st, p);    // byte-offset entries, as k_step expects
+        if (p.periodic) {
+            if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p);
+            else hipLaunchKernelGGL((k_fill<true, true, false>), gridx, block, lds, st, p);
+        } else if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<false, true, true>), gridx, block, lds, st, p);    // byte-offset entries, as k_step expects
         else hipLaunchKernelGGL((k_fill<false, true, false>), gridx, block, lds, st, p);
     } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false, false>), gridx, block, 0, st, p);
     else hipLaunchKernelGGL((k_fill<false, false, false>), gridx, block, 0, st, p);
