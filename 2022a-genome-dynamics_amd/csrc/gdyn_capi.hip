@@ -678,7 +678,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         }
     }
     if (tover) {
-        const unsigned cap = pick_tile_cap(need_t + need_t / 16 + 32);
+        const unsigned cap = pick_tile_cap(need_t + need_t / 32 + 32);
         // 128 KB dynamic + static part < 160 KB of LDS per CU.  Periodic tiles are whole rows of cells and pay the minimum
         // image per pair: with one resident block per CU they lose to the generic path (measured on S-1kb-250k)
         const unsigned cap_max = s->box_kind == GD_BOX_PERIODIC ? 5040u : 8192u;
