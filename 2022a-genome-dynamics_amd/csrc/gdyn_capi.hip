@@ -94,6 +94,7 @@ struct gd_system {
     int pcur = 0, ccur = 0;
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
+    float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
     uint32_t tile_hold = 0;        // chunks to stay in the larger tile class after an overflow
     uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
     uint32_t cpb = 1, tile_cap = 3280;
@@ -185,6 +186,7 @@ extern "C" int gd_destroy(gd_system *s)
     if (!s) return GD_OK;
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
     delete s;
     return GD_OK;
 }
@@ -227,32 +229,36 @@ extern "C" int gd_set_positions(gd_system *s, const double *xyz)
     return GD_OK;
 }
 
-static int fetch_positions(gd_system *s, std::vector<float4> &h, int quantize)
+// Snapshot download: gather to bead order and pack xyz on the device, one copy into a pinned staging buffer that
+// lives with the handle (a fresh pageable buffer per call costs page faults and a slower copy).
+static int fetch_xyz(gd_system *s, const float **out, int quantize)
 {
     HIPCHK(hipSetDevice(s->device));
-    const size_t RN = (size_t)s->R * s->N;
-    h.resize(RN);
-    gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->fout.p, s->N, s->Np, s->R, quantize, s->stream);
-    HIPCHK(hipMemcpyAsync(h.data(), s->fout.p, RN * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    const size_t n3 = (size_t)s->R * s->N * 3;
+    if (!s->h_stage) HIPCHK(hipHostMalloc((void **)&s->h_stage, n3 * sizeof(float), hipHostMallocDefault));
+    gd_launch_gather_xyz(s->pos[s->pcur].p, s->slot_of.p, (float *)s->fout.p, s->N, s->Np, s->R, quantize, s->stream);   // fout: R*N float4 >= n3 floats
+    HIPCHK(hipMemcpyAsync(s->h_stage, s->fout.p, n3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    *out = s->h_stage;
     return GD_OK;
 }
 
 extern "C" int gd_get_positions(gd_system *s, double *xyz)
 {
     if (!s || !xyz) return fail(GD_EINVAL, "gd_get_positions: NULL argument");
-    std::vector<float4> h;
-    GDCHK(fetch_positions(s, h, 0));
-    for (size_t i = 0; i < h.size(); i++) { xyz[3 * i] = h[i].x; xyz[3 * i + 1] = h[i].y; xyz[3 * i + 2] = h[i].z; }
+    const float *h = nullptr;
+    GDCHK(fetch_xyz(s, &h, 0));
+    const size_t n3 = (size_t)s->R * s->N * 3;
+    for (size_t i = 0; i < n3; i++) xyz[i] = h[i];
     return GD_OK;
 }
 
 extern "C" int gd_get_positions_f32(gd_system *s, float *xyz, int quantize)
 {
     if (!s || !xyz) return fail(GD_EINVAL, "gd_get_positions_f32: NULL argument");
-    std::vector<float4> h;
-    GDCHK(fetch_positions(s, h, quantize));
-    for (size_t i = 0; i < h.size(); i++) { xyz[3 * i] = h[i].x; xyz[3 * i + 1] = h[i].y; xyz[3 * i + 2] = h[i].z; }
+    const float *h = nullptr;
+    GDCHK(fetch_xyz(s, &h, quantize));
+    memcpy(xyz, h, (size_t)s->R * s->N * 3 * sizeof(float));
     return GD_OK;
 }
 

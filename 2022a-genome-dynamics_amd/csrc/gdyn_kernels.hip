@@ -1365,6 +1365,27 @@ __global__ void k_gather_positions(const float4 *pos, const unsigned *slot_of, f
     out[(size_t)r * N + o] = x;
 }
 
+// Snapshot download: bead order, xyz packed (12 bytes per bead cross PCIe), optional 2^-16 rounding on the device
+__global__ void k_gather_xyz(const float4 *pos, const unsigned *slot_of, float *out, unsigned N, unsigned Np, int quantize)
+{
+    const unsigned r = blockIdx.y, o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    float4 x = pos[(size_t)r * Np + slot_of[(size_t)r * N + o]];
+    if (quantize) {
+        x.x = rintf(x.x * 65536.0f) * (1.0f / 65536.0f);
+        x.y = rintf(x.y * 65536.0f) * (1.0f / 65536.0f);
+        x.z = rintf(x.z * 65536.0f) * (1.0f / 65536.0f);
+    }
+    float *q = out + ((size_t)r * N + o) * 3;
+    q[0] = x.x; q[1] = x.y; q[2] = x.z;
+}
+
+void gd_launch_gather_xyz(const float4 *pos, const unsigned *slot_of, float *out, unsigned N, unsigned Np, unsigned R, int quantize,
+                          hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gather_xyz, dim3((N + 255) / 256, R), dim3(256), 0, st, pos, slot_of, out, N, Np, quantize);
+}
+
 void gd_launch_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np, unsigned R,
                                 int quantize, hipStream_t st)
 {

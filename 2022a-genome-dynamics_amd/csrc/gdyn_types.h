@@ -203,6 +203,8 @@ struct BuildParams {
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
 void gd_launch_finalize(const StepParams &p, int reduce_only, hipStream_t st);
 void gd_launch_build(const BuildParams &p, hipStream_t st);
+void gd_launch_gather_xyz(const float4 *pos, const unsigned *slot_of, float *out, unsigned N, unsigned Np, unsigned R, int quantize,
+                          hipStream_t st);
 void gd_launch_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np,
                                 unsigned R, int quantize, hipStream_t st);
 void gd_launch_identity(unsigned *orig, unsigned *slot_of, unsigned N, unsigned Np, unsigned R, hipStream_t st);

@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--beads", type=int, default=30000)
     ap.add_argument("--replicas", type=int, default=64, help="replicas batched per GPU")
-    ap.add_argument("--equil", type=int, default=2000, help="untimed relaxation steps before warmup")
+    ap.add_argument("--equil", type=int, default=20000,
+                    help="untimed relaxation steps before warmup (SURVEY 8d cfg3: 20 000 from the random-walk start)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skin", type=float, default=0.0)
     ap.add_argument("--interval", type=int, default=0)
@@ -167,11 +168,18 @@ def main():
     # interphase_logging_interval = 100 steps, a quantised snapshot every interphase_sampling_interval = 1000 steps
     # (config_entries.inc:81-82); 1000 extra steps, not part of `value`
     farm.barrier()
+    sys_.positions_f32(quantize=True)      # (a driver takes thousands of snapshots: not the first, cold one)
     t1 = time.perf_counter()
+    _dbg = []
     for k in range(10):
+        _t = time.perf_counter()
         sys_.run(100, dt, kT, seed=seed, flags=flags)
+        _t2 = time.perf_counter()
         e_obs = sys_.energy()
+        _dbg.append((round((_t2 - _t) * 1e3, 2), round((time.perf_counter() - _t2) * 1e3, 2)))
+    _t = time.perf_counter()
     snap = sys_.positions_f32(quantize=True)
+    if os.environ.get("BENCH_DEBUG"): print("obs loop", _dbg, "snapshot ms", round((time.perf_counter() - _t) * 1e3, 2), file=sys.stderr)
     obs_rate = N * R * 1000 / (time.perf_counter() - t1)
     del snap, e_obs
 
