@@ -874,9 +874,12 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             const double cut_now = pair_cutoff(s) * (s->pair.scale_by_bead_scale ? bead_scale_bound(s, nullptr, 0) : 1.0);
             const double lim = 0.5 * (s->rv - cut_now), d = std::sqrt((double)maxd2);
             if (lim > 0 && d > 0) {
-                // displacement grows ~ sqrt(steps): aim at 60% of the skin at the end of an interval
+                // displacement grows ~ sqrt(steps): aim at 85% of the skin at the end of an interval. The maximum over ~2e6 beads
+                // fluctuates by only ~3.5% between intervals (sigma / sqrt(2 ln n)), so 15% is a 4-sigma margin; a violation
+                // costs one rolled-back chunk and is remembered (K_bad)
                 const double ratio = d / lim;
-                double knew = (double)s->K * (0.7 / ratio) * (0.7 / ratio);
+                static const double target = getenv("GDYN_K_TARGET") ? atof(getenv("GDYN_K_TARGET")) : 0.85;
+                double knew = (double)s->K * (target / ratio) * (target / ratio);
                 knew = std::min(knew, 2.0 * s->K + 1);
                 s->K = (uint32_t)std::max(1.0, std::min(200.0, std::floor(knew)));
             } else if (d == 0) s->K = std::min(200u, s->K * 2);
