@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--equil", type=int, default=20000,
                     help="untimed relaxation steps before warmup (SURVEY 8d cfg3: 20 000 from the random-walk start)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-state", default="", help="write the relaxed positions (after --equil) to this .npy and exit")
+    ap.add_argument("--load-state", default="", help="start from relaxed positions saved by --save-state (no relaxation "
+                    "launches: used for the committed rocprof summaries, so that kernel averages cover the timed state only)")
     ap.add_argument("--skin", type=float, default=0.0)
     ap.add_argument("--interval", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on the GPU node; gloo for rehearsals")
@@ -152,9 +155,14 @@ def main():
     dt, kT = info["timestep"], info["temperature"]
 
     sys_.begin_phase()
-    if a.equil > 0:
+    if a.load_state:
+        sys_.set_positions(np.load(a.load_state))
+    elif a.equil > 0:
         sys_.run(a.equil, dt, kT, seed=seed + 17, flags=0)      # relaxation: static scales / wall
         sys_.begin_phase()
+    if a.save_state:
+        np.save(a.save_state, sys_.positions())
+        return
     if a.warmup > 0:
         sys_.run(a.warmup, dt, kT, seed=seed, flags=flags)
 
