@@ -176,8 +176,9 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply (v_mad_u64_u32) per product instead of separate high and low halves
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
         c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
