@@ -852,7 +852,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 if (s->K == 1) {
                     if (s->skin > 8) return fail(GD_ESTATE, "gd_run: Verlet skin cannot cover one step (timestep too large?)");
                     s->skin *= 1.5;
-                } else { s->K_bad = s->K; s->K_bad_ttl = 64; s->K = std::max(1u, s->K - std::max(1u, s->K / 4)); }
+                } else { s->K_bad = s->K; s->K_bad_ttl = 64; s->K = std::max(1u, s->K - std::max(1u, s->K / 4)); }   // (a gentler cut, K/8 for 32 chunks, violates again sooner: measured 1% slower)
             }
             s->timing.step_launches -= std::min<uint64_t>(s->timing.step_launches, (uint64_t)chunk);
             continue;
