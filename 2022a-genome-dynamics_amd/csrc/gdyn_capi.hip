@@ -94,6 +94,7 @@ struct gd_system {
     int pcur = 0, ccur = 0;
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
+    bool has_inner = false; gd_inner_sphere inner{};
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
     uint32_t tile_hold = 0;        // chunks to stay in the larger tile class after an overflow
     uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
@@ -376,6 +377,15 @@ extern "C" int gd_set_ellipsoid_wall(gd_system *s, const gd_wall *w)
     return GD_OK;
 }
 
+extern "C" int gd_set_inner_sphere_wall(gd_system *s, const gd_inner_sphere *w)
+{
+    if (!s || !w) return fail(GD_EINVAL, "gd_set_inner_sphere_wall: NULL argument");
+    if (!valid_pq(w->p_a, w->q_a) || !valid_pq(w->p_b, w->q_b)) return fail(GD_EINVAL, "gd_set_inner_sphere_wall: unsupported softcore powers");
+    if (!(w->radius > 0)) return fail(GD_EINVAL, "gd_set_inner_sphere_wall: radius must be positive");
+    s->inner = *w; s->has_inner = true;
+    return GD_OK;
+}
+
 extern "C" int gd_set_scaling(gd_system *s, double bi, double bt, double oi, double ot)
 {
     if (!s) return fail(GD_EINVAL, "gd_set_scaling: NULL system");
@@ -581,6 +591,13 @@ static void fill_common(gd_system *s, StepParams &p)
         p.wall.enabled = 1; p.wall.packing_spring = (float)w.packing_spring;
         for (int k = 0; k < 3; k++) p.wall.spring[k] = w.semiaxes_spring[k];
         p.wall.mobility = w.mobility;
+    }
+    if (s->has_inner) {
+        const gd_inner_sphere &w = s->inner;
+        p.wall.inner_enabled = 1; p.wall.in_radius = (float)w.radius;
+        p.wall.in_eps_a = (float)w.eps_a; p.wall.in_sigma_a = (float)w.sigma_a; p.wall.in_eps_b = (float)w.eps_b; p.wall.in_sigma_b = (float)w.sigma_b;
+        p.wall.in_p_a = w.p_a; p.wall.in_q_a = w.q_a; p.wall.in_p_b = w.p_b; p.wall.in_q_b = w.q_b;
+        p.wall.in_wall_a = (float)w.wall_a_factor; p.wall.in_wall_b = (float)w.wall_b_factor; p.wall.in_spring = (float)w.spring;
     }
     p.scaling = ScaleP{s->has_scaling ? 1 : 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau};
     p.btab = s->btab.p; p.nbt = (int)s->n_bond_types;

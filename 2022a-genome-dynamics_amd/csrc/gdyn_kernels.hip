@@ -613,6 +613,29 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             }
         }
 
+        // ---- inner spherical wall (excluded core of the 4-sim-ab sphere model): soft repulsion outside, harmonic inside
+        if (p.wall.inner_enabled && (mask & TERM_WALL)) {
+            const float rr2 = xi.x * xi.x + xi.y * xi.y + xi.z * xi.z;
+            const float reach = p.wall.in_radius + 0.5f * fmaxf(p.wall.in_sigma_a, p.wall.in_sigma_b);
+            if (__builtin_amdgcn_ballot_w64(rr2 < reach * reach) != 0ull && rr2 > 0.f) {
+                const float inv_r = rsqrtf(rr2), rad = rr2 * inv_r, gap = rad - p.wall.in_radius;
+                const float r2 = gap * gap, gs = gap * inv_r;          // delta = gs * x
+                float e = 0.f, fr = 0.f;
+                if (gap > 0.f) {
+                    const float sa = 0.5f * p.wall.in_sigma_a, sb = 0.5f * p.wall.in_sigma_b;
+                    const float wa = 0.5f * (abi.x + p.wall.in_wall_a), wb = 0.5f * (abi.y + p.wall.in_wall_b);
+                    float ea, fa, eb, fb;
+                    softcore(p.wall.in_eps_a, sa > 0.f ? 1.0f / (sa * sa) : 0.f, p.wall.in_p_a, p.wall.in_q_a, r2, ea, fa);
+                    softcore(p.wall.in_eps_b, sb > 0.f ? 1.0f / (sb * sb) : 0.f, p.wall.in_p_b, p.wall.in_q_b, r2, eb, fb);
+                    e = wa * ea + wb * eb; fr = wa * fa + wb * fb;
+                } else if (gap < 0.f) {
+                    e = 0.5f * p.wall.in_spring * r2; fr = -p.wall.in_spring;
+                }
+                F.x += fr * gs * xi.x; F.y += fr * gs * xi.y; F.z += fr * gs * xi.z;
+                if (MODE == GD_MODE_ENERGY) E += e;
+            }
+        }
+
         if (MODE == GD_MODE_STEP) {
             GD_STAMP(5);  // wall
             // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi

@@ -76,6 +76,10 @@ struct WallP {
     int scaled, enabled;
     float packing_spring;
     double spring[3], mobility;
+    // inner spherical wall (gd_set_inner_sphere_wall)
+    int inner_enabled;
+    float in_radius, in_eps_a, in_sigma_a, in_eps_b, in_sigma_b, in_wall_a, in_wall_b, in_spring;
+    int in_p_a, in_q_a, in_p_b, in_q_b;
 };
 
 struct BondType {               // 32 bytes: two 16-byte LDS reads per bond

@@ -10,7 +10,6 @@
 //  * `md::random_engine` is taken to be std::mt19937_64 (as the stage-3/5 drivers spell it out);
 //  * the integrator seed is left at "micromd's default" by the reference (simulation_driver.cc:211-216): 0 here;
 //  * softcore_potential<P> (one-argument form) is softcore<P,3>;
-//  * the sphere driver's inner wall (inner_wall_radius >= 1e-6, default 0 = absent) is not supported.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -184,15 +183,13 @@ private:
         gd_bond_params bond{};
         bond.kind = GD_POT_HARMONIC; bond.k_a = _config.bond_spring;
         for (auto const &c : _chains) chk(gd_add_bond_range(_sys, &bond, (uint32_t)c.start, (uint32_t)c.end, 1));
-        if (_geo == geometry::sphere) setup_forcefield_outer_wall();
+        if (_geo == geometry::sphere) { setup_forcefield_outer_wall(); setup_forcefield_inner_wall(); }
     }
 
     // sphere/src/simulation_driver.cc:141-181: wall factors (0,1), half diameters, energies times the multiplier,
     // harmonic restoring force outside; a static sphere is the ellipsoid with three equal, frozen semiaxes
     void setup_forcefield_outer_wall()
     {
-        if (!(_config.inner_wall_radius < 1e-6))
-            throw std::runtime_error("inner_wall_radius > 0 (inner sphere wall) is not supported");
         gd_wall wall{};
         wall.eps_a = _config.outer_wall_multiplier * _config.a_core_repulsion; wall.sigma_a = _config.a_core_diameter; wall.p_a = 2; wall.q_a = 3;
         wall.eps_b = _config.outer_wall_multiplier * _config.b_core_repulsion; wall.sigma_b = _config.b_core_diameter; wall.p_b = 8; wall.q_b = 3;
@@ -200,6 +197,20 @@ private:
         wall.packing_spring = _config.outer_wall_spring;
         for (int k = 0; k < 3; k++) wall.init_semiaxes[k] = _config.outer_wall_radius;
         chk(gd_set_ellipsoid_wall(_sys, &wall));
+    }
+
+    // sphere/src/simulation_driver.cc:184-228: an excluded core (absent below a radius of 1e-6): harmonic push-out inside,
+    // the wall-type soft repulsion (factors (0,1), half diameters, energies times the multiplier) outside
+    void setup_forcefield_inner_wall()
+    {
+        if (_config.inner_wall_radius < 1e-6) return;
+        gd_inner_sphere wall{};
+        wall.radius = _config.inner_wall_radius;
+        wall.eps_a = _config.inner_wall_multiplier * _config.a_core_repulsion; wall.sigma_a = _config.a_core_diameter; wall.p_a = 2; wall.q_a = 3;
+        wall.eps_b = _config.inner_wall_multiplier * _config.b_core_repulsion; wall.sigma_b = _config.b_core_diameter; wall.p_b = 8; wall.q_b = 3;
+        wall.wall_a_factor = 0; wall.wall_b_factor = 1;
+        wall.spring = _config.inner_wall_spring;
+        chk(gd_set_inner_sphere_wall(_sys, &wall));
     }
 
     // straight rods with the centroid at a random point (box :147-180; sphere :238-275)

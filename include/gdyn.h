@@ -167,6 +167,23 @@ typedef struct {
 
 int gd_set_ellipsoid_wall(gd_system *sys, const gd_wall *w);
 
+/* Inner spherical wall around the origin, an excluded core
+ * (4-sim-ab/sphere/src/simulation_driver.cc:184-228, active when inner_wall_radius >= 1e-6):
+ *   beads outside it: make_sphere_outward_forcefield(a_w*softcore<p_a,q_a>{eps_a, sigma_a/2} + b_w*softcore<p_b,q_b>{eps_b, sigma_b/2})
+ *                     on the displacement from the nearest surface point, a_w=(a_i+wall_a_factor)/2, b_w likewise;
+ *   beads inside it:  make_sphere_inward_forcefield(harmonic_potential{spring}) pushing them back out.
+ * sigma_* are FULL diameters; fold inner_wall_multiplier into eps_*.  Static (no dynamics, no reaction).
+ * Part of the GD_TERM_WALL term; independent of gd_set_ellipsoid_wall. */
+typedef struct {
+    double  radius;
+    double  eps_a, sigma_a, eps_b, sigma_b;
+    int32_t p_a, q_a, p_b, q_b;
+    double  wall_a_factor, wall_b_factor;
+    double  spring;
+} gd_inner_sphere;
+
+int gd_set_inner_sphere_wall(gd_system *sys, const gd_inner_sphere *w);
+
 /* --------------------------------------------------- per-step context (a11) */
 
 /* bead_scale(t) = 1-(1-init)exp(-t/tau), same for bond_scale

@@ -81,6 +81,8 @@ struct gd_system {
     psrc_t ps[MAX_POINT_SOURCES];
     int has_wall;
     gd_wall wall;
+    int has_inner;
+    gd_inner_sphere inner;
     int has_scaling;
     double bs_init, bs_tau, bo_init, bo_tau;
     ctx_t *ctx;
@@ -420,6 +422,16 @@ int gd_add_point_source(gd_system *s, int kind, double k, double b, const double
         for (uint32_t i = 0; i < nt; i++) ps->mask[targets[i]] = 1;
     }
     s->nps++;
+    return GD_OK;
+}
+
+/* 4-sim-ab/sphere/src/simulation_driver.cc:184-228 */
+int gd_set_inner_sphere_wall(gd_system *s, const gd_inner_sphere *w)
+{
+    if (!s || !w) return fail(GD_EINVAL, "gd_set_inner_sphere_wall: NULL argument");
+    if (!valid_pq(w->p_a, w->q_a) || !valid_pq(w->p_b, w->q_b)) return fail(GD_EINVAL, "gd_set_inner_sphere_wall: unsupported softcore powers");
+    if (!(w->radius > 0)) return fail(GD_EINVAL, "gd_set_inner_sphere_wall: radius must be positive");
+    s->inner = *w; s->has_inner = 1;
     return GD_OK;
 }
 
@@ -811,6 +823,27 @@ static double compute(gd_system *s, uint32_t r, uint32_t mask, double *F, int wa
             }
         }
         if (F) memcpy(c->react, react, sizeof react);
+    }
+    if ((mask & GD_TERM_WALL) && s->has_inner) {
+        /* inner sphere: displacement from the nearest surface point is (r - R) along the radius */
+        const gd_inner_sphere *w = &s->inner;
+        for (uint32_t i = 0; i < N; i++) {
+            const double *p = x + 3 * i;
+            double r = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+            if (!(r > 0)) continue;                       /* at the centre: no direction */
+            double g = (r - w->radius) / r, delta[3] = { g * p[0], g * p[1], g * p[2] };
+            double r2 = (r - w->radius) * (r - w->radius), e = 0, fr = 0;
+            if (r > w->radius) {                          /* outside the core: soft repulsion, half diameters */
+                double wa = 0.5 * (s->a[i] + w->wall_a_factor), wb = 0.5 * (s->b[i] + w->wall_b_factor), ea, fa, eb, fb;
+                softcore_eval(w->eps_a, 0.5 * w->sigma_a, w->p_a, w->q_a, r2, &ea, &fa);
+                softcore_eval(w->eps_b, 0.5 * w->sigma_b, w->p_b, w->q_b, r2, &eb, &fb);
+                e = wa * ea + wb * eb; fr = wa * fa + wb * fb;
+            } else if (r < w->radius) {                   /* inside: harmonic, back to the surface */
+                e = 0.5 * w->spring * r2; fr = -w->spring;
+            }
+            E += e;
+            if (F && fr != 0) for (int k = 0; k < 3; k++) F[3 * i + k] += fr * delta[k];
+        }
     }
     return E;
 }

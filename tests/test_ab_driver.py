@@ -33,8 +33,11 @@ def _inputs(tmp, geo):
                seed=5, bond_spring=70.0)
     if geo == "box":
         cfg.update(box_size=2.0)
-    else:
+    elif geo == "sphere":
         cfg.update(outer_wall_radius=1.2, outer_wall_multiplier=2.0, outer_wall_spring=50.0)
+    else:       # "shell": sphere with the excluded core of sphere/src/simulation_driver.cc:184-228
+        cfg.update(outer_wall_radius=1.3, outer_wall_multiplier=2.0, outer_wall_spring=50.0, inner_wall_radius=0.5,
+                   inner_wall_multiplier=1.5, inner_wall_spring=40.0)
     (tmp / "config.json").write_text(json.dumps(cfg))
     return cfg
 
@@ -54,7 +57,10 @@ def _python_ab(lib, oracle, cfg, geo, seed):
         if geo == "box":
             center = np.array([rnd.uniform(0, d["box_size"]) for _ in range(3)])
         else:
-            center = np.array([rnd.uniform(-d["outer_wall_radius"], d["outer_wall_radius"]) for _ in range(3)])
+            while True:     # rejection of centres inside the core (sphere/src/simulation_driver.cc:246-251)
+                center = np.array([rnd.uniform(-d["outer_wall_radius"], d["outer_wall_radius"]) for _ in range(3)])
+                if not math.sqrt(center[0] * center[0] + center[1] * center[1] + center[2] * center[2]) < d.get("inner_wall_radius", 0.0):
+                    break
         z = rnd.normals(3)
         inv = 1 / math.sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2])
         direction = np.array([z[0] * inv, z[1] * inv, z[2] * inv])
@@ -71,10 +77,14 @@ def _python_ab(lib, oracle, cfg, geo, seed):
     bond = g.System.bond_params(g.POT_HARMONIC, k_a=d["bond_spring"])
     for c in range(CHAINS):
         s.add_bond_range(bond, c * LEN, (c + 1) * LEN, 1)
-    if geo == "sphere":
+    if geo != "box":
         m = d["outer_wall_multiplier"]
         s.set_ellipsoid_wall(m * d["a_core_repulsion"], d["a_core_diameter"], m * d["b_core_repulsion"], d["b_core_diameter"], 0.0, 1.0,
                              d["outer_wall_spring"], (0.0, 0.0, 0.0), 0.0, (d["outer_wall_radius"],) * 3, scale_by_bead_scale=False)
+        if d.get("inner_wall_radius", 0.0) >= 1e-6:
+            mi = d["inner_wall_multiplier"]
+            s.set_inner_sphere_wall(d["inner_wall_radius"], mi * d["a_core_repulsion"], d["a_core_diameter"], mi * d["b_core_repulsion"],
+                                    d["b_core_diameter"], 0.0, 1.0, d["inner_wall_spring"])
     s.set_positions(x)
     s.begin_phase()
     pos, energy = {0: s.positions()[0].copy()}, {0: float(s.energy()[0]) / N}
@@ -111,7 +121,7 @@ def _check(tmp, lib, oracle, driver, geo, atol, env=None, seed_arg=None):
     # file layout of 4-sim-ab/box/src/simulation/simulation_store.cc:20-76
     saved = json.loads(_tool("strings", tmp / "out.h5", "/metadata/config"))
     assert saved["seed"] == seed and saved["mobility"] == 1.0 and saved["beads_filename"] == cfg["beads_filename"]
-    assert ("box_size" in saved) == (geo == "box") and ("outer_wall_radius" in saved) == (geo == "sphere")
+    assert ("box_size" in saved) == (geo == "box") and ("outer_wall_radius" in saved) == (geo != "box")
     ab = _dataset(tmp, "/metadata/ab_factors")
     assert ab.shape == (N, 2) and ab[0].tolist() == [1, 0] and ab[LEN].tolist() == [0, 1] and ab[7 * LEN].tolist() == [0.5, 0.5]
     assert _dataset(tmp, "/metadata/chain_ranges").tolist() == [[c * LEN, (c + 1) * LEN] for c in range(CHAINS)]
@@ -129,9 +139,9 @@ def _check(tmp, lib, oracle, driver, geo, atol, env=None, seed_arg=None):
         assert "H5T_IEEE_F32LE" in p and "SCALEOFFSET" in p and "DEFLATE { LEVEL 1 }" in p
 
 
-@pytest.mark.parametrize("geo", ["box", "sphere"])
+@pytest.mark.parametrize("geo", ["box", "sphere", "shell"])
 def test_ab_driver_on_oracle(tmp_path, oracle, geo):
-    drv = _make_oracle(f"gd_ab_{geo}", tmp_path)
+    drv = _make_oracle("gd_ab_box" if geo == "box" else "gd_ab_sphere", tmp_path)
     _check(tmp_path, oracle, oracle, drv, geo, atol=0, env=_env(os.path.join(ROOT, "oracle")), seed_arg=11 if geo == "box" else None)
 
 
@@ -145,15 +155,9 @@ def test_ab_driver_errors(tmp_path, oracle):
     r = subprocess.run([str(drv), str(tmp_path / "missing.json"), str(tmp_path / "out.h5")], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "cannot open config file" in r.stderr       # main.cc:50-54
     assert subprocess.run([str(drv)], capture_output=True, text=True, env=env).returncode == 1
-    sph = _make_oracle("gd_ab_sphere", tmp_path)
-    cfg = _inputs(tmp_path, "sphere")
-    cfg["inner_wall_radius"] = 0.3
-    (tmp_path / "config.json").write_text(json.dumps(cfg))
-    r = subprocess.run([str(sph), str(tmp_path / "config.json"), str(tmp_path / "out.h5")], capture_output=True, text=True, env=env)
-    assert r.returncode == 1 and "inner" in r.stderr
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geo", ["box", "sphere"])
+@pytest.mark.parametrize("geo", ["box", "sphere", "shell"])
 def test_ab_driver_on_gpu(tmp_path, hip, oracle, geo):
-    _check(tmp_path, hip, oracle, _make(f"gd_ab_{geo}", ".", "../csrc", "gdyn"), geo, atol=2e-4)
+    _check(tmp_path, hip, oracle, _make("gd_ab_box" if geo == "box" else "gd_ab_sphere", ".", "../csrc", "gdyn"), geo, atol=2e-4)

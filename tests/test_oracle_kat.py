@@ -141,6 +141,46 @@ def test_sphere_wall_exact(oracle):
     assert s.forces()[0, 0, 2] == pytest.approx(-5000 * 0.1, rel=1e-9)
 
 
+def test_inner_sphere_wall_exact_and_gradient(oracle):
+    # excluded core (4-sim-ab/sphere/src/simulation_driver.cc:184-228): outside, the wall-type soft repulsion on the
+    # gap to the surface (half diameters, factors (0,1)); inside, a harmonic push back out; F = -grad U throughout
+    Rin, eps, sa, sb, K = 0.8, 3.0, 0.30, 0.24, 40.0
+    n = np.array([2.0, -1.0, 2.0]) / 3.0
+    for a, b in ((1.0, 0.0), (0.0, 1.0), (0.5, 0.5)):
+        for gap in (0.02, 0.08, 0.119, 0.2, -0.1, -0.4):
+            s = g.System(oracle, 1, 1)
+            s.set_bead_params(a=np.array([a]), b=np.array([b]))
+            s.set_inner_sphere_wall(Rin, eps, sa, eps, sb, 0.0, 1.0, K)
+            s.set_positions((n * (Rin + gap))[None])
+            if gap > 0:
+                ua, ub = gap / (sa / 2), gap / (sb / 2)
+                wa, wb = 0.5 * a, 0.5 * (b + 1.0)
+                e_ref = wa * (eps * (1 - ua ** 2) ** 3 if ua < 1 else 0.0) + wb * (eps * (1 - ub ** 8) ** 3 if ub < 1 else 0.0)
+                f_ref = wa * (eps * 6 / (sa / 2) * (1 - ua ** 2) ** 2 * ua if ua < 1 else 0.0) \
+                    + wb * (eps * 24 / (sb / 2) * (1 - ub ** 8) ** 2 * ub ** 7 if ub < 1 else 0.0)
+            else:
+                e_ref, f_ref = 0.5 * K * gap * gap, -K * gap
+            assert s.energy()[0] == pytest.approx(e_ref, rel=1e-9, abs=1e-13)
+            assert np.allclose(s.forces()[0, 0], f_ref * n, rtol=1e-9, atol=1e-12)      # always pushed outwards
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(40, 3)) * 0.6
+    s = g.System(oracle, 40, 1)
+    s.set_bead_params(a=rng.random(40), b=rng.random(40))
+    s.set_inner_sphere_wall(Rin, eps, sa, eps, sb, 0.0, 1.0, K)
+    s.set_positions(x[None])
+    F = s.forces(g.TERM_WALL)[0]
+    h = 1e-6
+    for i in (0, 7, 23):
+        for k in range(3):
+            xp, xm = x.copy(), x.copy()
+            xp[i, k] += h; xm[i, k] -= h
+            s.set_positions(xp[None]); ep = s.energy(g.TERM_WALL)[0]
+            s.set_positions(xm[None]); em = s.energy(g.TERM_WALL)[0]
+            assert F[i, k] == pytest.approx(-(ep - em) / (2 * h), rel=1e-5, abs=1e-6)
+    with pytest.raises(g.GdynError):
+        s.set_inner_sphere_wall(0.0, eps, sa, eps, sb, 0.0, 1.0, K)
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_force_is_minus_gradient(oracle, name):
     s, *_ = build(oracle, name)

@@ -288,3 +288,31 @@ def test_runtime_softcore_powers_and_unpackable_factors(hip, oracle, powers):
     assert np.abs(out[0][0] - out[1][0]).max() <= FORCE_RTOL * scale
     assert np.allclose(out[0][1], out[1][1], rtol=1e-5)
     assert np.abs(out[0][2] - out[1][2]).max() <= POS_ATOL_20STEP
+
+
+def test_inner_sphere_wall_matches_oracle(hip, oracle):
+    """The excluded core of the 4-sim-ab sphere model (gd_set_inner_sphere_wall): forces, energy and a short trajectory."""
+    rng = np.random.default_rng(11)
+    n = 3000
+    x = rng.normal(size=(n, 3))
+    x *= (rng.random(n) ** (1 / 3) * 1.6 / np.linalg.norm(x, axis=1))[:, None]      # uniform in a ball: some inside the core
+    a = (rng.random(n) < 0.5).astype(float)
+    systems = []
+    for lib in (hip, oracle):
+        s = g.System(lib, n, 1)
+        s.set_bead_params(a=a, b=1.0 - a, mobility=np.ones(n))
+        s.set_pair_softcore(2.0, 0.30, 2.0, 0.24, 2, 3, 8, 3, mix=True)
+        s.set_ellipsoid_wall(4.0, 0.30, 4.0, 0.24, 0.0, 1.0, 50.0, (0.0,) * 3, 0.0, (1.7,) * 3, scale_by_bead_scale=False)
+        s.set_inner_sphere_wall(0.6, 3.0, 0.30, 3.0, 0.24, 0.0, 1.0, 40.0)
+        s.set_positions(x[None])
+        s.begin_phase()
+        systems.append(s)
+    sh, so = systems
+    fo, fw = so.forces(), so.forces(g.TERM_WALL)
+    assert np.abs(fw).max() > 1.0
+    assert np.abs(sh.forces() - fo).max() <= FORCE_RTOL * np.abs(fo).max()
+    assert np.abs(sh.forces(g.TERM_WALL) - fw).max() <= FORCE_RTOL * np.abs(fw).max()
+    assert sh.energy()[0] == pytest.approx(so.energy()[0], rel=ENERGY_RTOL)
+    for s in systems:
+        s.run(10, 1e-5, 1.0, seed=SEED)
+    assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
