@@ -96,7 +96,7 @@ ABI_SYMBOLS = [
     "gd_last_error", "gd_backend_name", "gd_create", "gd_destroy", "gd_set_positions", "gd_get_positions",
     "gd_get_positions_f32", "gd_set_bead_params", "gd_set_pair_softcore", "gd_add_bond_range",
     "gd_add_bond_pairs", "gd_set_dynamic_pairs", "gd_add_bending_range", "gd_add_point_source",
-    "gd_set_ellipsoid_wall", "gd_set_inner_sphere_wall", "gd_set_scaling", "gd_get_context", "gd_begin_phase", "gd_set_context",
+    "gd_set_ellipsoid_wall", "gd_set_inner_sphere_wall", "gd_set_pair_softwell", "gd_set_scaling", "gd_get_context", "gd_begin_phase", "gd_set_context",
     "gd_run", "gd_compute_energy", "gd_compute_forces", "gd_search_pairs", "gd_set_tuning",
     "gd_get_timing", "gd_get_stream", "gd_debug_bench",
 ]
@@ -139,6 +139,7 @@ class Lib:
                                           C.POINTER(C.c_uint32), C.c_uint32]
         d.gd_set_ellipsoid_wall.argtypes = [C.c_void_p, C.POINTER(Wall)]
         d.gd_set_inner_sphere_wall.argtypes = [C.c_void_p, C.POINTER(InnerSphere)]
+        d.gd_set_pair_softwell.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_uint32]
         d.gd_set_scaling.argtypes = [C.c_void_p] + [C.c_double] * 4
         d.gd_get_context.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Context)]
         d.gd_begin_phase.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -273,6 +274,10 @@ class System:
                  int(scale_by_bead_scale), packing_spring, (C.c_double * 3)(*semiaxes_spring), mobility,
                  (C.c_double * 3)(*init_semiaxes))
         self.lib.check(self.lib.dll.gd_set_ellipsoid_wall(self._h, C.byref(w)))
+
+    def set_pair_softwell(self, energy, decay, cutoff, targets):
+        t = np.ascontiguousarray(targets, dtype=np.uint32)
+        self.lib.check(self.lib.dll.gd_set_pair_softwell(self._h, energy, decay, cutoff, t.ctypes.data if len(t) else None, len(t)))
 
     def set_inner_sphere_wall(self, radius, eps_a, sigma_a, eps_b, sigma_b, wall_a_factor, wall_b_factor, spring,
                               p_a=2, q_a=3, p_b=8, q_b=3):

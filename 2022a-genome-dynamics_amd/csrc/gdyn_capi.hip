@@ -95,6 +95,8 @@ struct gd_system {
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
     bool has_inner = false; gd_inner_sphere inner{};
+    uint32_t sw_n = 0; double sw_eps = 0, sw_decay = 1, sw_cut = 0;     // droplet attraction (gd_set_pair_softwell)
+    DevBuf<unsigned> sw_targets; DevBuf<double> sw_esum;
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
     uint32_t tile_hold = 0;        // chunks to stay in the larger tile class after an overflow
     uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
@@ -375,6 +377,38 @@ extern "C" int gd_set_ellipsoid_wall(gd_system *s, const gd_wall *w)
     for (auto &c : s->hctx) memcpy(c.semi, w->init_semiaxes, sizeof c.semi);
     s->ctx_dirty = true;
     return GD_OK;
+}
+
+extern "C" int gd_set_pair_softwell(gd_system *s, double energy, double decay, double cutoff, const uint32_t *targets, uint32_t n)
+{
+    if (!s || (n && !targets)) return fail(GD_EINVAL, "gd_set_pair_softwell: NULL argument");
+    if (n > 4096) return fail(GD_EINVAL, "gd_set_pair_softwell: at most 4096 targets");
+    if (n && (!(decay > 0) || !(cutoff > 0))) return fail(GD_EINVAL, "gd_set_pair_softwell: decay and cutoff must be positive");
+    for (uint32_t k = 0; k < n; k++) if (targets[k] >= s->N) return fail(GD_EINVAL, "gd_set_pair_softwell: target %u out of range", k);
+    HIPCHK(hipSetDevice(s->device));
+    s->sw_n = 0;
+    if (n) {
+        HIPCHK(s->sw_targets.resize(n, false));
+        HIPCHK(hipMemcpy(s->sw_targets.p, targets, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(s->sw_esum.resize(s->R));
+        s->sw_n = n; s->sw_eps = energy; s->sw_decay = decay; s->sw_cut = cutoff;
+    }
+    return GD_OK;
+}
+
+// the droplet term of the step / force / energy evaluation that `p` describes (same positions, same buffers)
+static void launch_softwell(gd_system *s, const StepParams &p, int mode)
+{
+    SoftwellP q;
+    memset(&q, 0, sizeof q);
+    q.pos_in = p.pos_in; q.pos_out = p.pos_out; q.fout = s->fout.p; q.esum = s->sw_esum.p;
+    q.slot_of = s->slot_of.p; q.targets = s->sw_targets.p;
+    q.mob_o = s->mob_uniform >= 0.f ? nullptr : s->mob_o.p; q.mob_uniform = s->mob_uniform; q.dt = p.dt;
+    q.eps = (float)s->sw_eps; q.inv_d2 = (float)(1.0 / (s->sw_decay * s->sw_decay)); q.rc2 = (float)(s->sw_cut * s->sw_cut);
+    q.N = s->N; q.Np = s->Np; q.R = s->R; q.M = s->sw_n;
+    q.periodic = s->box_kind == GD_BOX_PERIODIC;
+    for (int k = 0; k < 3; k++) { q.box[k] = (float)s->box[k]; q.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
+    gd_launch_softwell(q, mode, s->stream);
 }
 
 extern "C" int gd_set_inner_sphere_wall(gd_system *s, const gd_inner_sphere *w)
@@ -832,6 +866,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 p.host_noise = host_noise ? s->noise.p + (size_t)(done + k + q) * RN * 3 : nullptr;
                 p.record_disp = (q == n - 1);
                 gd_launch_step(p, GD_MODE_STEP, s->stream);
+                if (s->sw_n) launch_softwell(s, p, 0);
                 s->pcur ^= 1; s->ccur ^= 1;
             }
             HIPCHK(hipEventRecord(e1, s->stream));
@@ -918,11 +953,18 @@ extern "C" int gd_compute_energy(gd_system *s, uint32_t mask, double *energy)
     fill_common(s, p);
     p.term_mask = mask;
     gd_launch_step(p, GD_MODE_ENERGY, s->stream);
+    const bool droplet = s->sw_n && (mask & GD_TERM_PAIR);
+    std::vector<double> esw(s->R, 0.0);
+    if (droplet) {
+        HIPCHK(hipMemsetAsync(s->sw_esum.p, 0, s->R * sizeof(double), s->stream));
+        launch_softwell(s, p, 2);
+        HIPCHK(hipMemcpyAsync(esw.data(), s->sw_esum.p, s->R * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    }
     std::vector<double> part((size_t)s->R * s->nblk);
     HIPCHK(hipMemcpyAsync(part.data(), s->epart.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     for (uint32_t r = 0; r < s->R; r++) {
-        double e = 0;
+        double e = esw[r];
         for (uint32_t b = 0; b < s->nblk; b++) e += part[(size_t)r * s->nblk + b];
         energy[r] = e;
     }
@@ -939,6 +981,7 @@ extern "C" int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
     p.term_mask = mask;
     HIPCHK(hipMemsetAsync(s->react_part.p, 0, s->react_part.n * sizeof(float4), s->stream));
     gd_launch_step(p, GD_MODE_FORCE, s->stream);
+    if (s->sw_n && (mask & GD_TERM_PAIR)) launch_softwell(s, p, 1);
     if (s->has_wall) { gd_launch_finalize(p, 1, s->stream); s->ccur ^= 1; }
     const size_t RN = (size_t)s->R * s->N;
     std::vector<float4> h(RN);

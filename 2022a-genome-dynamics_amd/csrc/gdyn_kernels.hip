@@ -1373,6 +1373,76 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
     else hipLaunchKernelGGL((k_fill<false, false, false>), gridx, block, 0, st, p);
 }
 
+// ------------------------------------------------------------- droplet attraction
+// U = -eps / (1 + (r/decay)^6), r < cutoff, between all pairs of the (few hundred) target beads of a replica
+// (simulation_driver_forcefield.cc:153-178; potential form: documented choice, include/gdyn.h).  A separate small
+// kernel after k_step: the update is linear in the force, so x_out += mu dt F_droplet on top of k_step's result is
+// the same step; the forces are evaluated on the same (old) positions.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_softwell(const SoftwellP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_x[];
+    const unsigned r = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    const unsigned *__restrict__ so = p.slot_of + (size_t)r * p.N;
+    const float4 *__restrict__ rpos = p.pos_in + (size_t)r * p.Np;
+    for (unsigned q = threadIdx.x; q < p.M; q += 256) s_x[q] = rpos[so[p.targets[q]]];
+    __syncthreads();
+    float3 F = make_float3(0.f, 0.f, 0.f);
+    float E = 0.f;
+    unsigned bead = 0;
+    if (t < p.M) {
+        bead = p.targets[t];
+        const float4 xi = s_x[t];
+        for (unsigned q = 0; q < p.M; q++) {
+            const float4 xj = s_x[q];
+            float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+            if (p.periodic) d = min_image(d, p.box, p.inv_box);
+            const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+            if (q != t && p.targets[q] != bead && r2 < p.rc2) {
+                const float u2 = r2 * p.inv_d2, u6 = u2 * u2 * u2, inv_den = 1.0f / (1.0f + u6);
+                const float fr = -6.0f * p.eps * u2 * u2 * p.inv_d2 * inv_den * inv_den;
+                F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
+                E += -0.5f * p.eps * inv_den;        // every pair is visited from both ends
+            }
+        }
+    }
+    if (MODE == 0) {
+        if (t < p.M) {
+            const float mu_dt = (p.mob_o ? p.mob_o[bead] : p.mob_uniform) * p.dt;
+            float4 *o = p.pos_out + (size_t)r * p.Np + so[bead];
+            float4 x = *o;
+            x.x += mu_dt * F.x; x.y += mu_dt * F.y; x.z += mu_dt * F.z;
+            *o = x;
+        }
+    } else if (MODE == 1) {
+        if (t < p.M) {
+            float4 *o = p.fout + (size_t)r * p.N + bead;
+            float4 f = *o;
+            f.x += F.x; f.y += F.y; f.z += F.z;
+            *o = f;
+        }
+    } else {
+        double e = wave_sum_d((double)E);
+        if ((threadIdx.x & 63) == 0 && e != 0.0) atomicAdd(&p.esum[r], e);
+    }
+}
+
+void gd_launch_softwell(const SoftwellP &p, int mode, hipStream_t st)
+{
+    const dim3 grid((p.M + 255) / 256, p.R), block(256);
+    const size_t lds = (size_t)p.M * sizeof(float4);
+    static bool once = false;
+    if (!once) {
+        once = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softwell<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softwell<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softwell<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    }
+    if (mode == 0) hipLaunchKernelGGL(k_softwell<0>, grid, block, lds, st, p);
+    else if (mode == 1) hipLaunchKernelGGL(k_softwell<1>, grid, block, lds, st, p);
+    else hipLaunchKernelGGL(k_softwell<2>, grid, block, lds, st, p);
+}
+
 // ------------------------------------------------------------------- misc
 
 __global__ void k_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np, int quantize)

@@ -207,6 +207,20 @@ struct BuildParams {
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
 void gd_launch_finalize(const StepParams &p, int reduce_only, hipStream_t st);
 void gd_launch_build(const BuildParams &p, hipStream_t st);
+// Droplet attraction among a small set of target beads (gd_set_pair_softwell): all pairs, one thread per target.
+struct SoftwellP {
+    const float4 *pos_in;       // positions the forces are evaluated on (slot order)
+    float4 *pos_out;            // mode 0: x_out += mu dt F  (the Euler-Maruyama update is linear in F)
+    float4 *fout;               // mode 1: forces by bead index, added
+    double *esum;               // mode 2: [R] energy, added
+    const unsigned *slot_of, *targets;
+    const float *mob_o;         // per-bead mobility, or NULL with mob_uniform
+    float mob_uniform, dt, eps, inv_d2, rc2;
+    unsigned N, Np, R, M;
+    int periodic;
+    float box[3], inv_box[3];
+};
+void gd_launch_softwell(const SoftwellP &p, int mode, hipStream_t st);
 void gd_launch_gather_xyz(const float4 *pos, const unsigned *slot_of, float *out, unsigned N, unsigned Np, unsigned R, int quantize,
                           hipStream_t st);
 void gd_launch_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np,

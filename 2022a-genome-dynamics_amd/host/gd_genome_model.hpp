@@ -65,8 +65,13 @@ inline gd_system *build_genome_system(trajectory_store &store, simulation_config
         std::vector<uint32_t> pairs;
         for (auto const &bond : store.load_nucleolus_bonds()) { pairs.push_back((uint32_t)bond.nor_index); pairs.push_back((uint32_t)bond.nuc_index); }
         if (!pairs.empty()) chk(gd_add_bond_pairs(sys, &nuc, pairs.data(), (uint32_t)(pairs.size() / 2)));
-        if (config.nucleolus_droplet_energy != 0)
-            throw std::runtime_error("nucleolus_droplet_energy != 0 (softwell droplet force) is not supported yet");
+        // nucleolar droplet attraction, only when its energy is set (simulation_driver_forcefield.cc:153-178)
+        if (config.nucleolus_droplet_energy != 0) {
+            std::vector<uint32_t> nucleolar;
+            for (auto const &r : nucleoli) for (std::size_t i = r.begin; i < r.end; i++) nucleolar.push_back((uint32_t)i);
+            chk(gd_set_pair_softwell(sys, config.nucleolus_droplet_energy, config.nucleolus_droplet_decay, config.nucleolus_droplet_cutoff,
+                                     nucleolar.data(), (uint32_t)nucleolar.size()));
+        }
         // nuclear membrane
         gd_wall wall{};
         wall.eps_a = config.a_core_repulsion; wall.sigma_a = config.a_core_diameter; wall.p_a = 2; wall.q_a = 3;

@@ -1,6 +1,6 @@
 // gd_h5tool -- small command-line companion of the trajectory store (used by the tests and for demos; the
 // reference creates its input files with Python/h5py, 5-sim-genome/src/prepare, which is not available here).
-//   gd_h5tool make-input <out.h5> <config.json> <chroms.tsv> <ab.f64> <positions.f64> [<nucleolus_bonds.u32>]
+//   gd_h5tool make-input <out.h5> <config.json> <chroms.tsv> <ab.f64> <positions.f64> [<nucleolus_bonds.u32> [<nucleolus_ranges.u32>]]
 //        chroms.tsv rows: name start end centromere_start centromere_end; raw little-endian arrays (N,2)/(N,3)
 //   gd_h5tool steps <file> <phase>                     numerically ordered step list
 //   gd_h5tool positions <file> <phase> <step> <out.f64>
@@ -30,7 +30,7 @@ int main(int argc, char **argv)
 {
     try {
         std::string const cmd = argc > 1 ? argv[1] : "";
-        if (cmd == "make-input" && (argc == 7 || argc == 8)) {
+        if (cmd == "make-input" && argc >= 7 && argc <= 9) {
             auto const cfg = slurp(argv[3]);
             std::vector<gd::chromosome_range> chroms;
             std::ifstream tsv(argv[4]);
@@ -47,10 +47,15 @@ int main(int argc, char **argv)
             for (std::size_t i = 0; i < n; i++) abv[i] = {ab[2 * i], ab[2 * i + 1]};
             std::vector<gd::nucleolus_bond> bonds;
             std::vector<gd::index_range> nranges;
-            if (argc == 8) {
+            if (argc >= 8) {
                 auto const raw = slurp(argv[7]);
                 auto const *p = reinterpret_cast<std::uint32_t const *>(raw.data());
                 for (std::size_t k = 0; k + 1 < raw.size() / sizeof(std::uint32_t); k += 2) bonds.push_back({p[k], p[k + 1]});
+            }
+            if (argc == 9) {
+                auto const raw = slurp(argv[8]);
+                auto const *p = reinterpret_cast<std::uint32_t const *>(raw.data());
+                for (std::size_t k = 0; k + 1 < raw.size() / sizeof(std::uint32_t); k += 2) nranges.push_back({p[k], p[k + 1]});
             }
             gd::trajectory_store store(argv[2], /*create=*/true);
             store.save_metadata(std::string(cfg.begin(), cfg.end()), abv, chroms, nranges, bonds);

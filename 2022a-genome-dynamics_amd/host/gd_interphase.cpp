@@ -10,7 +10,7 @@
 //
 // Differences from the reference, by construction: fp32 device arithmetic and a Philox noise stream (micromd's
 // generator is not reproducible); `spacestep` must be 0; the softwell droplet force
-// (nucleolus_droplet_energy != 0) is not implemented yet.
+// (nucleolus_droplet_energy != 0) uses a documented choice of micromd's potential form (include/gdyn.h).
 #include <algorithm>
 #include <array>
 #include <cmath>

@@ -96,6 +96,18 @@ typedef struct {
 
 int gd_set_pair_softcore(gd_system *sys, const gd_pair_softcore *p);
 
+/* Nucleolar droplet attraction (simulation_driver_forcefield.cc:153-178, only added when
+ * nucleolus_droplet_energy != 0):
+ *   make_neighbor_pairwise_forcefield(apply_cutoff(softwell_potential<6>{energy, decay_distance}, cutoff))
+ *       .set_neighbor_distance(cutoff).set_neighbor_targets(idx)
+ * acts between every pair of TARGET beads closer than `cutoff`:
+ *   U(r) = -energy / (1 + (r/decay)^6)  for r < cutoff, 0 beyond (plain truncation).
+ * micromd's softwell_potential / apply_cutoff are not in the tree: sign and truncation are a DOCUMENTED
+ * CHOICE.  Part of GD_TERM_PAIR; minimum image in periodic boxes.
+ * At most 4096 targets; n_targets = 0 removes the term. */
+int gd_set_pair_softwell(gd_system *sys, double energy, double decay, double cutoff,
+                         const uint32_t *targets, uint32_t n_targets);
+
 /* ------------------------------------------------------------- bonded (a6) */
 
 enum {

@@ -83,6 +83,7 @@ struct gd_system {
     gd_wall wall;
     int has_inner;
     gd_inner_sphere inner;
+    uint32_t sw_n; uint32_t *sw_targets; double sw_eps, sw_decay, sw_cut;
     int has_scaling;
     double bs_init, bs_tau, bo_init, bo_tau;
     ctx_t *ctx;
@@ -267,7 +268,7 @@ int gd_destroy(gd_system *s)
     for (int i = 0; i < MAX_DYN; i++) free(s->dyn[i].pairs);
     for (int i = 0; i < s->nps; i++) free(s->ps[i].mask);
     free(s->x); free(s->a); free(s->b); free(s->mob); free(s->bend);
-    free(s->bi); free(s->bj); free(s->btype); free(s->ti); free(s->te); free(s->ctx);
+    free(s->bi); free(s->bj); free(s->btype); free(s->ti); free(s->te); free(s->ctx); free(s->sw_targets);
     free(s);
     return GD_OK;
 }
@@ -422,6 +423,23 @@ int gd_add_point_source(gd_system *s, int kind, double k, double b, const double
         for (uint32_t i = 0; i < nt; i++) ps->mask[targets[i]] = 1;
     }
     s->nps++;
+    return GD_OK;
+}
+
+/* simulation_driver_forcefield.cc:153-178 (documented choice of the potential form, see include/gdyn.h) */
+int gd_set_pair_softwell(gd_system *s, double energy, double decay, double cutoff, const uint32_t *targets, uint32_t n)
+{
+    if (!s || (n && !targets)) return fail(GD_EINVAL, "gd_set_pair_softwell: NULL argument");
+    if (n > 4096) return fail(GD_EINVAL, "gd_set_pair_softwell: at most 4096 targets");
+    if (n && (!(decay > 0) || !(cutoff > 0))) return fail(GD_EINVAL, "gd_set_pair_softwell: decay and cutoff must be positive");
+    for (uint32_t k = 0; k < n; k++) if (targets[k] >= s->N) return fail(GD_EINVAL, "gd_set_pair_softwell: target %u out of range", k);
+    free(s->sw_targets); s->sw_targets = NULL; s->sw_n = 0;
+    if (n) {
+        s->sw_targets = malloc(n * sizeof(uint32_t));
+        if (!s->sw_targets) return fail(GD_ENOMEM, "gd_set_pair_softwell: out of memory");
+        memcpy(s->sw_targets, targets, n * sizeof(uint32_t));
+        s->sw_n = n; s->sw_eps = energy; s->sw_decay = decay; s->sw_cut = cutoff;
+    }
     return GD_OK;
 }
 
@@ -761,6 +779,21 @@ static double compute(gd_system *s, uint32_t r, uint32_t mask, double *F, int wa
             }
         }
         E += pc.E;
+    }
+    if ((mask & GD_TERM_PAIR) && s->sw_n) {     /* droplet attraction among the target beads, all pairs */
+        double inv_d2 = 1.0 / (s->sw_decay * s->sw_decay), rc2 = s->sw_cut * s->sw_cut;
+        for (uint32_t a = 0; a < s->sw_n; a++) for (uint32_t b = a + 1; b < s->sw_n; b++) {
+            uint32_t i = s->sw_targets[a], j = s->sw_targets[b];
+            if (i == j) continue;
+            double d[3] = { x[3 * i] - x[3 * j], x[3 * i + 1] - x[3 * j + 1], x[3 * i + 2] - x[3 * j + 2] };
+            if (s->box_kind == GD_BOX_PERIODIC) min_image(s, d);
+            double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            if (!(r2 < rc2)) continue;
+            double u2 = r2 * inv_d2, u6 = u2 * u2 * u2, den = 1.0 + u6;
+            E += -s->sw_eps / den;
+            double fr = -6.0 * s->sw_eps * u2 * u2 * inv_d2 / (den * den);      /* F_i = fr * (x_i - x_j): attraction */
+            if (F) for (int k = 0; k < 3; k++) { F[3 * i + k] += fr * d[k]; F[3 * j + k] -= fr * d[k]; }
+        }
     }
     if (mask & GD_TERM_BOND)
         for (uint32_t k = 0; k < s->nbonds; k++) eval_bond(s, c, &s->bt[s->btype[k]], s->bi[k], s->bj[k], x, F, &E);

@@ -48,13 +48,19 @@ def _config(radius):
     return c
 
 
-def _inputs(tmp):
+NUC = (540, 600)           # nucleolar particles of the droplet variant: the last 60 beads; bonded to "NOR" beads 100..159
+
+
+def _inputs(tmp, droplet=False):
     rng = np.random.default_rng(7)
     lens = wl.chain_lengths(N)
     a, b = wl.ab_types(N, rng)
     radius = 0.27 * (N / (8 * 0.3)) ** (1 / 3)
     x0 = wl.confined_random_walks(lens, radius, 0.2, np.random.default_rng(8))
     cfg = _config(radius)
+    if droplet:
+        cfg.update(nucleolus_droplet_energy=0.6, nucleolus_droplet_decay=0.2, nucleolus_droplet_cutoff=0.4, nucleolus_mobility=0.7,
+                   nucleolus_bond_spring=5.0, nucleolus_bond_length=0.1)
     (tmp / "config.json").write_text(json.dumps(cfg))
     st = 0
     rows, ranges = [], []
@@ -65,8 +71,24 @@ def _inputs(tmp):
     (tmp / "chroms.tsv").write_text("\n".join(rows) + "\n")
     np.stack([a, b], axis=1).astype("<f8").tofile(tmp / "ab.f64")
     x0.astype("<f8").tofile(tmp / "pos.f64")
+    extra = []
+    if droplet:     # the nucleolar beads are not part of any chromosome: shorten the last chains' table entries accordingly
+        rows2, ranges2 = [], []
+        for row, (b0, b1) in zip(rows, ranges):
+            if b0 >= NUC[0]:
+                continue
+            b1 = min(b1, NUC[0])
+            f = row.split()
+            rows2.append(f"{f[0]} {b0} {b1} {b0 + (b1 - b0) // 2} {b0 + (b1 - b0) // 2 + 1}")
+            ranges2.append((b0, b1))
+        rows, ranges = rows2, ranges2
+        (tmp / "chroms.tsv").write_text("\n".join(rows) + "\n")
+        bonds = np.array([[100 + k, NUC[0] + k] for k in range(NUC[1] - NUC[0])], dtype="<u4")
+        bonds.tofile(tmp / "nbonds.u32")
+        np.array([NUC], dtype="<u4").tofile(tmp / "nranges.u32")
+        extra = [str(tmp / "nbonds.u32"), str(tmp / "nranges.u32")]
     subprocess.check_call([os.path.join(HOST, "gd_h5tool"), "make-input", str(tmp / "traj.h5"), str(tmp / "config.json"),
-                           str(tmp / "chroms.tsv"), str(tmp / "ab.f64"), str(tmp / "pos.f64")])
+                           str(tmp / "chroms.tsv"), str(tmp / "ab.f64"), str(tmp / "pos.f64"), *extra])
     return cfg, a, b, x0, ranges, radius
 
 
@@ -79,10 +101,14 @@ def _positions(tmp, phase, step):
     return np.fromfile(tmp / "out.f64", dtype="<f8").reshape(-1, 3)
 
 
-def _python_driver(lib, oracle, cfg, a, b, x0q, ranges):
+def _python_driver(lib, oracle, cfg, a, b, x0q, ranges, droplet=False):
     """The same ABI call sequence as gd_interphase.cpp, issued from Python; returns {(phase, step): (positions, context)}."""
     s = g.System(lib, N, 1)
-    s.set_bead_params(a=a, b=b, mobility=np.full(N, cfg["chromatin_mobility"]))
+    mob = np.full(N, cfg["chromatin_mobility"])
+    if droplet:
+        mob[NUC[0]:] = 1.0                          # particles outside every chromosome keep the default mobility ...
+        mob[NUC[0]:NUC[1]] = cfg["nucleolus_mobility"]      # ... nucleolar ones get theirs (simulation_driver_particles.cc:28-35)
+    s.set_bead_params(a=a, b=b, mobility=mob)
     s.set_pair_softcore(cfg["a_core_repulsion"], cfg["a_core_diameter"], cfg["b_core_repulsion"], cfg["b_core_diameter"], 2, 3, 8, 3,
                         mix=True, scale_by_bead_scale=True)
     chain = g.System.bond_params(g.POT_SEMISPRING, k_a=cfg["a_core_bond_spring"], l_a=cfg["a_core_bond_length"],
@@ -92,6 +118,11 @@ def _python_driver(lib, oracle, cfg, a, b, x0q, ranges):
     for (b0, b1) in ranges:
         s.add_bond_range(chain, b0, b1, 1)
         s.add_bond_range(loop, b0, b1, 2)
+    if droplet:
+        nuc = g.System.bond_params(g.POT_SEMISPRING, k_a=cfg["nucleolus_bond_spring"], l_a=cfg["nucleolus_bond_length"], scale_by_bond_scale=True)
+        s.add_bond_pairs(nuc, np.array([[100 + k, NUC[0] + k] for k in range(NUC[1] - NUC[0])], dtype=np.uint32))
+        s.set_pair_softwell(cfg["nucleolus_droplet_energy"], cfg["nucleolus_droplet_decay"], cfg["nucleolus_droplet_cutoff"],
+                            np.arange(NUC[0], NUC[1], dtype=np.uint32))
     semi = np.array(cfg["wall_init_semiaxes"], dtype=float)
     s.set_ellipsoid_wall(cfg["a_core_repulsion"], cfg["a_core_diameter"], cfg["b_core_repulsion"], cfg["b_core_diameter"],
                          cfg["wall_a_factor"], cfg["wall_b_factor"], cfg["wall_packing_spring"], cfg["wall_semiaxes_spring"],
@@ -146,8 +177,8 @@ def _python_driver(lib, oracle, cfg, a, b, x0q, ranges):
     return out, saved_contacts
 
 
-def _check_run(tmp, lib, oracle, driver, atol, env=None):
-    cfg, a, b, x0, ranges, radius = _inputs(tmp)
+def _check_run(tmp, lib, oracle, driver, atol, env=None, droplet=False):
+    cfg, a, b, x0, ranges, radius = _inputs(tmp, droplet)
     x0q = _positions(tmp, "relaxation", 0)
     assert np.array_equal(x0q, (np.rint(x0.astype(np.float32) * np.float32(65536)) / np.float32(65536)).astype(np.float64))
     log = subprocess.run([str(driver), str(tmp / "traj.h5")], capture_output=True, text=True, env=env)
@@ -158,7 +189,7 @@ def _check_run(tmp, lib, oracle, driver, atol, env=None):
     assert "\tt: " in lines[-1] and "\tR: " in lines[-1] and "\tE: " in lines[-1]
     assert _tool("steps", tmp / "traj.h5", "relaxation").split() == ["0", "20", "40"]
     assert _tool("steps", tmp / "traj.h5", "interphase").split() == ["0", "20", "40", "60"]
-    ref, ref_contacts = _python_driver(lib, oracle, cfg, a, b, x0q, ranges)
+    ref, ref_contacts = _python_driver(lib, oracle, cfg, a, b, x0q, ranges, droplet)
     for (phase, step), (pos, ctx) in ref.items():
         got = _positions(tmp, phase, step)
         assert np.abs(got - pos).max() <= atol, (phase, step)
@@ -194,6 +225,12 @@ def test_store_layout_and_driver_on_oracle(tmp_path, oracle):
         assert 'ATTRIBUTE "keys"' in meta
 
 
+def test_driver_with_nucleolar_droplet_on_oracle(tmp_path, oracle):
+    """nucleolus_droplet_energy != 0: nucleolar side beads, their bonds and mobility, and the droplet attraction among them."""
+    drv = _make_oracle("gd_interphase", tmp_path)
+    _check_run(tmp_path, oracle, oracle, drv, atol=0, env=_env(os.path.join(ROOT, "oracle")), droplet=True)
+
+
 def test_missing_config_key_is_an_error(tmp_path, oracle):
     drv = _make_oracle("gd_interphase", tmp_path)
     cfg, *_ = _inputs(tmp_path)
@@ -206,8 +243,9 @@ def test_missing_config_key_is_an_error(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-def test_driver_on_gpu(tmp_path, hip, oracle):
-    _check_run(tmp_path, hip, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), atol=2e-4)
+@pytest.mark.parametrize("droplet", [False, True])
+def test_driver_on_gpu(tmp_path, hip, oracle, droplet):
+    _check_run(tmp_path, hip, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), atol=2e-4, droplet=droplet)
 
 
 # ---------------------------------------------------------------------------------------------- gd_spindle

@@ -141,6 +141,47 @@ def test_sphere_wall_exact(oracle):
     assert s.forces()[0, 0, 2] == pytest.approx(-5000 * 0.1, rel=1e-9)
 
 
+def test_softwell_droplet_exact_and_gradient(oracle):
+    # nucleolar droplet attraction (simulation_driver_forcefield.cc:153-178): U = -eps / (1 + (r/decay)^6) for r < cutoff,
+    # between target beads only (documented choice of the form); F = -grad U; non-targets feel nothing
+    eps, dec, cut = 1.5, 0.2, 0.4
+    n = np.array([1.0, -2.0, 2.0]) / 3.0
+    for r in (0.05, 0.19, 0.2, 0.3, 0.399, 0.401, 0.8):
+        s = g.System(oracle, 3, 1)
+        s.set_pair_softwell(eps, dec, cut, [0, 1])
+        s.set_positions(np.array([[0.0, 0.0, 0.0], r * n, 0.1 * n])[None])       # bead 2 sits between them, not a target
+        u6 = (r / dec) ** 6
+        e_ref = -eps / (1 + u6) if r < cut else 0.0
+        f_ref = eps * 6 * (r / dec) ** 5 / dec / (1 + u6) ** 2 if r < cut else 0.0      # magnitude of the attraction
+        assert s.energy()[0] == pytest.approx(e_ref, rel=1e-12, abs=1e-15)
+        F = s.forces()[0]
+        assert np.allclose(F[0], f_ref * n, rtol=1e-10, atol=1e-13) and np.allclose(F[1], -f_ref * n, rtol=1e-10, atol=1e-13)
+        assert np.all(F[2] == 0)
+        assert s.energy(g.TERM_ALL & ~g.TERM_PAIR)[0] == 0.0                     # part of the pair term
+    rng = np.random.default_rng(4)
+    x = rng.random((30, 3)) * 0.8
+    tg = rng.choice(30, size=12, replace=False)
+    for box in (None, (0.9, 0.9, 0.9)):
+        s = g.System(oracle, 30, 1, box=box)
+        s.set_pair_softwell(eps, dec, cut, tg)
+        s.set_positions(x[None])
+        F = s.forces()[0]
+        assert np.allclose(F.sum(axis=0), 0, atol=1e-12)
+        assert np.all(F[np.setdiff1d(np.arange(30), tg)] == 0)
+        h = 1e-6
+        for i in tg[:4]:
+            for k in range(3):
+                xp, xm = x.copy(), x.copy()
+                xp[i, k] += h; xm[i, k] -= h
+                s.set_positions(xp[None]); ep = s.energy()[0]
+                s.set_positions(xm[None]); em = s.energy()[0]
+                assert F[i, k] == pytest.approx(-(ep - em) / (2 * h), rel=1e-5, abs=1e-6)
+    s.set_pair_softwell(0.0, dec, cut, [])                                        # removable
+    assert s.energy()[0] == 0.0
+    with pytest.raises(g.GdynError):
+        s.set_pair_softwell(eps, dec, cut, [31])
+
+
 def test_inner_sphere_wall_exact_and_gradient(oracle):
     # excluded core (4-sim-ab/sphere/src/simulation_driver.cc:184-228): outside, the wall-type soft repulsion on the
     # gap to the surface (half diameters, factors (0,1)); inside, a harmonic push back out; F = -grad U throughout

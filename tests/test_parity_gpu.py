@@ -316,3 +316,35 @@ def test_inner_sphere_wall_matches_oracle(hip, oracle):
     for s in systems:
         s.run(10, 1e-5, 1.0, seed=SEED)
     assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
+
+
+@pytest.mark.parametrize("uniform_mobility", [True, False])
+def test_softwell_droplet_matches_oracle(hip, oracle, uniform_mobility):
+    """Nucleolar droplet attraction (gd_set_pair_softwell) on top of the interphase force field: forces, energy, trajectory."""
+    sh, info = wl.genome_interphase(hip, n_beads=4000)
+    so, _ = wl.genome_interphase(oracle, n_beads=4000)
+    rng = np.random.default_rng(2)
+    tg = np.sort(rng.choice(4000, size=300, replace=False))
+    mob = np.ones(4000) if uniform_mobility else rng.uniform(0.5, 1.5, size=4000)
+    x = so.positions()
+    x[0, tg] = x[0, tg[0]] + 0.25 * rng.normal(size=(300, 3))           # a clump, so that many target pairs are in range
+    for s in (sh, so):
+        s.set_bead_params(mobility=mob)
+        s.set_pair_softwell(0.8, 0.2, 0.4, tg)
+        s.set_positions(x)
+        s.begin_phase()
+    fo = so.forces()
+    fsw = fo - _without_softwell_forces(so, tg)
+    assert np.abs(fsw).max() > 0.5
+    assert np.abs(sh.forces() - fo).max() <= FORCE_RTOL * np.abs(fo).max()
+    assert sh.energy()[0] == pytest.approx(so.energy()[0], rel=ENERGY_RTOL * 5)
+    for s in (sh, so):
+        s.run(10, 1e-5, 1.0, seed=SEED, flags=g.RUN_WALL_DYNAMICS)
+    assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
+
+
+def _without_softwell_forces(s, tg):
+    s.set_pair_softwell(0.0, 0.2, 0.4, [])
+    f = s.forces()
+    s.set_pair_softwell(0.8, 0.2, 0.4, tg)
+    return f
