@@ -273,8 +273,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
 
     // every independent per-bead load is issued up front, ahead of the tile staging and the barrier,
     // so their latencies overlap (the kernel is latency-bound, not ALU-bound)
-    // thread -> bead assignment: the build sorted each block's beads by pair-list length, so the 64 lanes
-    // of a wave run (almost) the same number of list batches instead of waiting for their longest list
 #if GD_ABL == 30
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime(), acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -282,9 +280,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     // stay scalar loads; wave 0 also starts its full-context and reaction-partial loads first
     const long long ctx_step0 = p.ctx_in[r].step;
     const int ctx_pending0 = p.ctx_in[r].pending;
-    // ---- prologue, ordered for the in-order vmcnt counter: first everything that does not depend on the thread->bead
-    // permutation (bond table and tile go straight into LDS by DMA, nothing returns to registers), then the perm load
-    // and the per-bead loads; the noise then waits for the youngest loads only (a static vmcnt).
+    // ---- prologue, ordered for the in-order vmcnt counter: first everything that does not depend on the thread's
+    // bead (bond table and tile go straight into LDS by DMA, nothing returns to registers), then the per-bead loads;
+    // the noise then waits for the youngest loads only (a static vmcnt).
     if (TILED && GD_ABL != 12 && (GD_ABL != 33 || (blk & 3u) == 0)) {
         // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
         // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
@@ -311,11 +309,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
     }
     GD_STAMP(11);     // descriptor + DMA issue
-    const unsigned slot = blk * GD_BLOCK + (GD_ABL == 31 ? tid : (unsigned)p.perm[rbase + blk * GD_BLOCK + tid]);
-#if GD_ABL == 30
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GD_STAMP(7);      // perm arrived
-#endif
+    const unsigned slot = blk * GD_BLOCK + tid;      // (a per-block permutation balancing the waves by list length bought +4% on
+                                                     // unrelaxed, clumpy systems and nothing on relaxed ones: dropped)
     const bool valid = slot < p.N;
     const size_t g = rbase + slot;
     const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
@@ -1308,19 +1303,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         p.meta[g] = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
     }
     GD_FSTAMP(5);     // padding, meta
-    // block-local counting sort of the beads by list batches (longest first) -> perm for k_step
-    {
-        __shared__ unsigned s_hist[32], s_off[32];
-        if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
-        __syncthreads();
-        const unsigned nb = slot < p.N ? min((min(cnt, p.W) + GD_UNROLL - 1u) / GD_UNROLL, 30u) : 0u;
-        const unsigned bin = slot < p.N ? 30u - nb : 31u;                 // pad slots last
-        const unsigned rank = atomicAdd(&s_hist[bin], 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) { unsigned run = 0; for (int b = 0; b < 32; b++) { s_off[b] = run; run += s_hist[b]; } }
-        __syncthreads();
-        p.perm[rbase + blk * GD_BLOCK + s_off[bin] + rank] = (unsigned short)threadIdx.x;
-    }
     unsigned long long c64 = min(cnt, p.W);
     for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o, 64);
     if (lane == 0) s_cnt[wid] = c64;
@@ -1330,7 +1312,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         for (int w = 0; w < GD_BLOCK / 64; w++) t += s_cnt[w];
         if (t) atomicAdd(&p.lcount[r], t);
     }
-    GD_FSTAMP(6);     // perm + count
+    GD_FSTAMP(6);     // count
 #if GD_ABL == 34
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *rec = p.dbg + ((size_t)blockIdx.x * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 16;

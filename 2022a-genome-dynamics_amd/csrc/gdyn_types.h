@@ -119,7 +119,6 @@ struct StepParams {
     const unsigned short *nbr16;        // tiled path: tile-local indices
     const TileDesc *tiles;              // [R][nblk]
     const unsigned *meta;               // bdeg | psmask << 8 | list length << 16
-    const unsigned short *perm;         // thread -> block-local slot, beads sorted by list length (balanced waves)
     unsigned W, WB;                     // list width (entries), bond adjacency width (entries, multiple of 4)
     float mob_uniform;                  // >= 0: every bead has this mobility (mob[] is not read)
     int tiled;                          // 1: LDS-tiled path
@@ -190,7 +189,6 @@ struct BuildParams {
     unsigned *badj;
     int4 *chain;
     unsigned *nbr, *meta;
-    unsigned short *perm;
     int has_bend, mob_is_uniform;
     unsigned short *nbr16;
     TileDesc *tiles;
