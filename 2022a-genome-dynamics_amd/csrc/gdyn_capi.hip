@@ -729,7 +729,8 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // keeps the larger class for a while, so the margin for the smaller class can be thin)
         unsigned want = pick_tile_cap(need_t + 24);
         if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
-        if (want != s->tile_cap && want <= 8192u) {
+        if (s->box_kind == GD_BOX_PERIODIC && want > 5040u) s->tiled_ok = false;      // (see the overflow branch below)
+        else if (want != s->tile_cap && want <= 8192u) {
             if (getenv("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
         }

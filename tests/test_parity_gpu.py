@@ -206,6 +206,13 @@ def test_full_size_genome_properties(hip):
 def test_full_size_1kb_properties(hip):
     """S-1kb-250k (periodic): internal forces sum to zero, noise has the right variance, descent at T=0."""
     s, info = wl.chromatin_1kb(hip, n_beads=250000)
+    res = {}
+    for path in ("generic", "tiled"):       # periodic LDS tiles (whole rows of cells, ~4 900 entries here: index-encoded lists)
+        s.set_tuning(kernel_path=PATHS[path])
+        res[path] = (s.forces(), s.energy())
+    assert np.abs(res["generic"][0] - res["tiled"][0]).max() <= 1e-5 * np.abs(res["generic"][0]).max()
+    assert np.allclose(res["generic"][1], res["tiled"][1], rtol=1e-6)
+    s.set_tuning(kernel_path=0)
     F = s.forces(g.TERM_PAIR | g.TERM_BOND | g.TERM_BEND | g.TERM_DYNAMIC)
     assert np.abs(F.sum(axis=1)).max() <= 2e-6 * np.abs(F).sum()
     x0 = s.positions()
