@@ -623,6 +623,7 @@ static void fill_common(gd_system *s, StepParams &p)
         p.wall.p_a = w.p_a; p.wall.q_a = w.q_a; p.wall.p_b = w.p_b; p.wall.q_b = w.q_b;
         p.wall.wall_a = (float)w.wall_a_factor; p.wall.wall_b = (float)w.wall_b_factor; p.wall.scaled = w.scale_by_bead_scale;
         p.wall.enabled = 1; p.wall.packing_spring = (float)w.packing_spring;
+        p.wall.fast2383 = (w.p_a == 2 && w.q_a == 3 && w.p_b == 8 && w.q_b == 3) ? 1 : 0;
         for (int k = 0; k < 3; k++) p.wall.spring[k] = w.semiaxes_spring[k];
         p.wall.mobility = w.mobility;
     }

@@ -239,6 +239,11 @@ __device__ __forceinline__ void apply_callback(DevCtx &c, const StepParams &p, u
 struct CtxF {
     float bead_scale, bond_scale, semi[3];
     long long step;
+    // block-uniform wall quantities, computed once by the thread that fills this struct
+    float inv_semi[3], inv_semi2[3];
+    float inv_bond_scale2;
+    float near2;            // a bead can touch the wall only if C + 1 >= near2 (see the wall section); <= 0: always
+    float w_inv_sa2, w_inv_sb2, w_ca, w_cb;     // soft wall (half diameters, bead scale): 1/s^2, 6 eps_a / sa^2, 24 eps_b / sb^2
 };
 
 // ------------------------------------------------------------------- k_step
@@ -346,6 +351,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             s_ctx.bead_scale = (float)c.bead_scale; s_ctx.bond_scale = (float)c.bond_scale;
             s_ctx.semi[0] = (float)c.semi[0]; s_ctx.semi[1] = (float)c.semi[1]; s_ctx.semi[2] = (float)c.semi[2];
             s_ctx.step = c.step;
+            s_ctx.inv_bond_scale2 = (float)(1.0 / (c.bond_scale * c.bond_scale));
+            if (p.wall.enabled) {
+                float smin = 3.4e38f;
+                for (int k = 0; k < 3; k++) {
+                    const float a = (float)c.semi[k];
+                    s_ctx.inv_semi[k] = 1.0f / a; s_ctx.inv_semi2[k] = 1.0f / (a * a); smin = fminf(smin, a);
+                }
+                const float wsc = p.wall.scaled ? (float)c.bead_scale : 1.0f;
+                const float sa = 0.5f * p.wall.sigma_a * wsc, sb = 0.5f * p.wall.sigma_b * wsc;
+                // A bead on the level set s E (s = sqrt(C+1) < 1) is at least (1-s) min(a,b,c) away from the surface
+                // (E contains s E + (1-s) min(a,b,c) B), so beyond the larger half diameter the wall force is exactly zero
+                const float sthr = 1.0f - fmaxf(sa, sb) / smin;
+                s_ctx.near2 = sthr > 0.f ? sthr * sthr * 0.999f : 0.f;
+                s_ctx.w_inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f; s_ctx.w_inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
+                s_ctx.w_ca = 6.0f * p.wall.eps_a * s_ctx.w_inv_sa2; s_ctx.w_cb = 24.0f * p.wall.eps_b * s_ctx.w_inv_sb2;
+            }
         }
     }
     // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
         if (GD_ABL != 13 && p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
             const unsigned deg = meta & 0xffu;
-            const float inv_bs2 = 1.0f / (s_ctx.bond_scale * s_ctx.bond_scale);
+            const float inv_bs2 = s_ctx.inv_bond_scale2;
             // four adjacency entries (one 16-byte chunk) per round: the partner positions are fetched together, so
             // their LDS / global latencies overlap instead of adding up bond by bond
             for (unsigned k0 = 0; k0 < deg; k0 += 4) {
@@ -564,34 +585,31 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         // ---- ellipsoid wall (a9): second-order nearest-surface construction
         // (5-sim-genome/src/analyze_lamina/geometry.py:13-28), conjugate form u = C/(B+sqrt(B^2-AC)).
         if (GD_ABL != 15 && p.wall.enabled && (mask & TERM_WALL)) {
-            const float ia = 1.0f / (s_ctx.semi[0] * s_ctx.semi[0]), ib = 1.0f / (s_ctx.semi[1] * s_ctx.semi[1]),
-                        ic = 1.0f / (s_ctx.semi[2] * s_ctx.semi[2]);
+            const float ia = s_ctx.inv_semi2[0], ib = s_ctx.inv_semi2[1], ic = s_ctx.inv_semi2[2];
             const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);
-            const float C = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z - 1.0f;
-            // A bead on the level set s E (s = sqrt(C+1) < 1) is at least (1-s) min(a,b,c) away from the surface
-            // (E contains s E + (1-s) min(a,b,c) B), so beyond half the larger wall diameter the force is exactly zero:
-            // waves of interior beads (the slots are cell-sorted) skip the nearest-point construction altogether.
-            const float reach = 0.5f * fmaxf(p.wall.sigma_a, p.wall.sigma_b) * (p.wall.scaled ? s_ctx.bead_scale : 1.0f);
-            const float smin = fminf(s_ctx.semi[0], fminf(s_ctx.semi[1], s_ctx.semi[2]));
-            const float sthr = 1.0f - reach / smin;
-            const bool near_wall = !(sthr > 0.f) || C + 1.0f >= sthr * sthr * 0.999f;
-            if (__builtin_amdgcn_ballot_w64(near_wall) != 0ull) {
+            const float C1 = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z, C = C1 - 1.0f;
+            // waves of interior beads (the slots are cell-sorted) skip the nearest-point construction altogether
+            if (__builtin_amdgcn_ballot_w64(C1 >= s_ctx.near2) != 0ull) {
             const float B = s1.x * s1.x + s1.y * s1.y + s1.z * s1.z;
             const float A = s1.x * s1.x * ia + s1.y * s1.y * ib + s1.z * s1.z * ic;
-            const float den = B + sqrtf(fmaxf(B * B - A * C, 0.f));
+            // (hardware sqrt / rcp, 1 ulp: the IEEE-exact sequences are ~10 instructions each)
+            const float den = B + __builtin_amdgcn_sqrtf(fmaxf(B * B - A * C, 0.f));
             if (den > 0.f && C != 0.f) {
-                const float u = C / den;
+                const float u = C * __builtin_amdgcn_rcpf(den);
                 const float3 dl = make_float3(u * s1.x, u * s1.y, u * s1.z);
                 const float r2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z;
                 float e = 0.f, fr = 0.f;
                 if (C < 0.f) {
-                    const float sc = p.wall.scaled ? s_ctx.bead_scale : 1.0f;
-                    const float sa = 0.5f * p.wall.sigma_a * sc, sb = 0.5f * p.wall.sigma_b * sc;
                     const float wa = 0.5f * (abi.x + p.wall.wall_a), wb = 0.5f * (abi.y + p.wall.wall_b);
-                    float ea, fa, eb, fb;
-                    softcore(p.wall.eps_a, sa > 0.f ? 1.0f / (sa * sa) : 0.f, p.wall.p_a, p.wall.q_a, r2, ea, fa);
-                    softcore(p.wall.eps_b, sb > 0.f ? 1.0f / (sb * sb) : 0.f, p.wall.p_b, p.wall.q_b, r2, eb, fb);
-                    e = wa * ea + wb * eb; fr = wa * fa + wb * fb;
+                    if (p.wall.fast2383 && MODE != GD_MODE_ENERGY) {
+                        // the wall's soft cores are the pair family (<2,3> + <8,3>, half diameters): branch-free form
+                        fr = softcore_2383(r2, s_ctx.w_inv_sa2, s_ctx.w_inv_sb2, wa * s_ctx.w_ca, wb * s_ctx.w_cb);
+                    } else {
+                        float ea, fa, eb, fb;
+                        softcore(p.wall.eps_a, s_ctx.w_inv_sa2, p.wall.p_a, p.wall.q_a, r2, ea, fa);
+                        softcore(p.wall.eps_b, s_ctx.w_inv_sb2, p.wall.p_b, p.wall.q_b, r2, eb, fb);
+                        e = wa * ea + wb * eb; fr = wa * fa + wb * fb;
+                    }
                 } else {
                     e = 0.5f * p.wall.packing_spring * r2; fr = -p.wall.packing_spring;
                 }
@@ -599,9 +617,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                     const float3 fw = make_float3(fr * dl.x, fr * dl.y, fr * dl.z);
                     F.x += fw.x; F.y += fw.y; F.z += fw.z;
                     // axial_reaction_k = -F_k q_k / a_k, q = contact point on the surface
-                    react.x = -fw.x * (xi.x - dl.x) / s_ctx.semi[0];
-                    react.y = -fw.y * (xi.y - dl.y) / s_ctx.semi[1];
-                    react.z = -fw.z * (xi.z - dl.z) / s_ctx.semi[2];
+                    react.x = -fw.x * (xi.x - dl.x) * s_ctx.inv_semi[0];
+                    react.y = -fw.y * (xi.y - dl.y) * s_ctx.inv_semi[1];
+                    react.z = -fw.z * (xi.z - dl.z) * s_ctx.inv_semi[2];
                 }
                 if (MODE == GD_MODE_ENERGY) E += e;
             }

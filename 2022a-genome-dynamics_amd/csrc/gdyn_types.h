@@ -74,6 +74,7 @@ struct WallP {
     int p_a, q_a, p_b, q_b;
     float wall_a, wall_b;
     int scaled, enabled;
+    int fast2383;               // the wall's soft cores are <2,3> + <8,3>: branch-free specialisation
     float packing_spring;
     double spring[3], mobility;
     // inner spherical wall (gd_set_inner_sphere_wall)
