@@ -95,6 +95,7 @@ struct gd_system {
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
     bool has_inner = false; gd_inner_sphere inner{};
+    bool has_softcore_bonds = false;
     uint32_t sw_n = 0; double sw_eps = 0, sw_decay = 1, sw_cut = 0;     // droplet attraction (gd_set_pair_softwell)
     DevBuf<unsigned> sw_targets; DevBuf<double> sw_esum;
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
@@ -525,10 +526,14 @@ static int finalize_topology(gd_system *s)
         adj[(size_t)dg[b.j] * N + b.j] = b.i | ((unsigned)b.type << GD_ADJ_SHIFT); dg[b.j]++;
     }
     std::vector<BondType> bt(std::max<size_t>(types.size(), 1));
+    s->has_softcore_bonds = false;
     for (size_t i = 0; i < types.size(); i++) {
         const gd_bond_params &p = types[i];
-        bt[i] = BondType{(float)p.k_a, (float)p.k_b, (float)p.l_a, (float)p.l_b, p.kind,
-                         (p.mix ? 1 : 0) | (p.scale_by_bond_scale ? 2 : 0) | (p.minimum_image ? 4 : 0), p.p | (p.q << 8), terms[i]};
+        const bool harmonic = p.kind == GD_POT_HARMONIC;     // U = K r^2 / 2 is the spring with rest length 0
+        bt[i] = BondType{(float)p.k_a, (float)p.k_b, harmonic ? 0.f : (float)p.l_a, harmonic ? 0.f : (float)p.l_b, p.kind,
+                         (p.mix ? 1 : 0) | (p.scale_by_bond_scale ? 2 : 0) | (p.minimum_image ? 4 : 0) | (terms[i] << 8), p.p | (p.q << 8),
+                         p.kind == GD_POT_SEMISPRING ? 0.f : -3.0e38f};
+        if (p.kind == GD_POT_SOFTCORE) s->has_softcore_bonds = true;
     }
     // bending: energy of the triplet starting at each bead
     std::vector<double> tE(N, 0.0);
@@ -635,7 +640,7 @@ static void fill_common(gd_system *s, StepParams &p)
         p.wall.in_wall_a = (float)w.wall_a_factor; p.wall.in_wall_b = (float)w.wall_b_factor; p.wall.in_spring = (float)w.spring;
     }
     p.scaling = ScaleP{s->has_scaling ? 1 : 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau};
-    p.btab = s->btab.p; p.nbt = (int)s->n_bond_types;
+    p.btab = s->btab.p; p.nbt = (int)s->n_bond_types; p.has_softcore_bonds = s->has_softcore_bonds ? 1 : 0;
     p.nps = (int)s->psrc.size();
     for (int q = 0; q < p.nps; q++) {
         p.ps[q].kind = s->psrc[q].kind; p.ps[q].k = (float)s->psrc[q].k; p.ps[q].b = (float)s->psrc[q].b;

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                     const unsigned ent = ents[u];
                     const unsigned j = ent & GD_ADJ_MASK;
                     const BondType bt = s_bt[(ent >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1)];
-                    if (!(mask & (unsigned)bt.term)) continue;
+                    if (!(mask & ((unsigned)bt.flags >> 8))) continue;
                     const float4 xj = xjs[u];
                     float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
                     if (PERIODIC && (bt.flags & 4)) d = min_image(d, p.box, p.inv_box);
@@ -521,8 +521,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                         K = a * bt.ka + b * bt.kb; l = a * bt.la + b * bt.lb;
                     }
                     if (bt.flags & 2) { K = K * inv_bs2; l = l * s_ctx.bond_scale; }
-                    float e, fr;
-                    bond_pot(bt.kind, K, l, bt.pq & 0xff, bt.pq >> 8, r2, e, fr);
+                    float e = 0.f, fr;
+                    if (p.has_softcore_bonds && bt.kind == POT_SOFTCORE) {
+                        softcore(K, 1.0f / (l * l), bt.pq & 0xff, bt.pq >> 8, r2, e, fr);
+                    } else {
+                        // harmonic / spring / semispring in one branch-free form: elongation x = r - l clamped from below
+                        const float inv_d = r2 > 0.0f ? __builtin_amdgcn_rsqf(r2) : 0.0f;     // hardware rsq, 1 ulp
+                        const float x = fmaxf(fmaf(r2, inv_d, -l), bt.xmin);
+                        fr = -K * x * inv_d;
+                        if (MODE == GD_MODE_ENERGY) e = 0.5f * K * x * x;
+                    }
                     F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
                     if (MODE == GD_MODE_ENERGY) E += 0.5f * e;
                 }

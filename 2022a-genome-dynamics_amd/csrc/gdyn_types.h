@@ -86,9 +86,10 @@ struct WallP {
 struct BondType {               // 32 bytes: two 16-byte LDS reads per bond
     float ka, kb, la, lb;
     int kind;
-    int flags;                  // mix | scaled << 1 | minimg << 2
+    int flags;                  // mix | scaled << 1 | minimg << 2 | term << 8
     int pq;                     // p | q << 8 (GD_POT_SOFTCORE)
-    int term;
+    float xmin;                 // lower clamp of the elongation r - l: 0 for the semispring, -inf otherwise
+                                // (harmonic = spring with l = 0, so one branch-free form covers the three)
 };
 
 struct PointSrc {
@@ -127,6 +128,7 @@ struct StepParams {
     int packed_ab;                      // 1: pos.w holds (a,b) as two fp16 (exactly representable)
     unsigned cpb;                       // blocks per replica per XCD (XCD-aware block mapping)
     unsigned tile_cap;                  // beads of LDS per block
+    int has_softcore_bonds;             // some bond set is a soft core (the glue pairs of the 1 kb model): rare path
     const unsigned *badj;               // chunked like the pair lists, 4 entries per chunk
     const int4 *chain;                  // slots of (i-2, i-1, i+1, i+2) or -1
     // context
