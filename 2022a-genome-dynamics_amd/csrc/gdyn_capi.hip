@@ -101,7 +101,7 @@ struct gd_system {
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
     uint32_t tile_hold = 0;        // chunks to stay in the larger tile class after an overflow
     uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
-    uint32_t cpb = 1, tile_cap = 3280;
+    uint32_t cpb = 1, tile_cap = 3312;
 
     // tuning / cadence
     double skin = 0.75;   // relative to the pair cutoff; 0.65..0.8 are within 3% of each other on S-genome-30k, smaller tiles leave more LDS margin
@@ -566,7 +566,7 @@ static int finalize_topology(gd_system *s)
     s->packed_ab = packable;
 
     HIPCHK(s->ab_o.resize(N)); HIPCHK(s->mob_o.resize(N)); HIPCHK(s->bendE_o.resize(N)); HIPCHK(s->psmask_o.resize(N));
-    HIPCHK(s->bdeg_o.resize(N)); HIPCHK(s->badj_o.resize(adj.size())); HIPCHK(s->chain_o.resize(N)); HIPCHK(s->btab.resize(GD_MAX_BOND_TYPES));   /* always the full 1 KiB table: k_step stages it with one DMA piece */
+    HIPCHK(s->bdeg_o.resize(N)); HIPCHK(s->badj_o.resize(adj.size())); HIPCHK(s->chain_o.resize(N)); HIPCHK(s->btab.resize(GD_MAX_BOND_TYPES));   /* always the full table: k_step stages it with one DMA piece */
     HIPCHK(hipMemcpy(s->ab_o.p, ab.data(), N * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->mob_o.p, mob.data(), N * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->bendE_o.p, bendE.data(), N * sizeof(float4), hipMemcpyHostToDevice));
@@ -707,8 +707,8 @@ static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (siz
 // (1.2 KB static LDS per block on top of the tile).
 static unsigned pick_tile_cap(unsigned need)
 {
-    // LDS is granted in 1280-byte granules (measured: 3264 entries fit 3 blocks, 3318 do not)
-    static std::vector<unsigned> caps = {3280u, 5040u, 8192u};
+    // LDS is granted in 1280-byte granules (measured with 1184 B of static LDS: 3264 entries fit 3 blocks, 3318 do not; 720 B now)
+    static std::vector<unsigned> caps = {3312u, 5072u, 8192u};
     static bool init = false;
     if (!init) {      // experiment hook: GDYN_TILE_CAPS=a,b,c
         if (const char *e = getenv("GDYN_TILE_CAPS")) { caps.clear(); for (const char *q = e; *q;) { caps.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
@@ -735,7 +735,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // keeps the larger class for a while, so the margin for the smaller class can be thin)
         unsigned want = pick_tile_cap(need_t + 24);
         if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
-        if (s->box_kind == GD_BOX_PERIODIC && want > 5040u) s->tiled_ok = false;      // (see the overflow branch below)
+        if (s->box_kind == GD_BOX_PERIODIC && want > 5072u) s->tiled_ok = false;      // (see the overflow branch below)
         else if (want != s->tile_cap && want <= 8192u) {
             if (getenv("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
@@ -745,7 +745,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         const unsigned cap = pick_tile_cap(need_t + need_t / 32 + 32);
         // 128 KB dynamic + static part < 160 KB of LDS per CU.  Periodic tiles are whole rows of cells and pay the minimum
         // image per pair: with one resident block per CU they lose to the generic path (measured on S-1kb-250k)
-        const unsigned cap_max = s->box_kind == GD_BOX_PERIODIC ? 5040u : 8192u;
+        const unsigned cap_max = s->box_kind == GD_BOX_PERIODIC ? 5072u : 8192u;
         if (cap <= cap_max) { s->tile_cap = cap; s->tile_hold = 4; }
         else s->tiled_ok = false;                // too dense for one tile: generic path
     }

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = td->len[k]; tst[k] = td->start[k]; tbase[k] = td->base[k]; }
-        if (wid == 0)       // the bond-type table (GD_MAX_BOND_TYPES x 32 B = one 1 KiB piece; the buffer is always that large)
+        if (wid == 0 && lane < 2 * GD_MAX_BOND_TYPES)       // the bond-type table: 32 B per type, 16 B per lane (the buffer always holds the full table)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)p.btab + lane),
                                              (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
 #pragma unroll

@@ -16,7 +16,8 @@
 #ifndef GD_BLOCK
 #define GD_BLOCK 512
 #endif
-#define GD_MAX_BOND_TYPES 32
+#define GD_MAX_BOND_TYPES 16   // distinct bond parameter sets (the reference models use <= 4 + the loop / glue slots); the
+                               // table lives in LDS next to the tile: every 16 bytes saved there are one more tile entry
 #define GD_MAX_POINT_SOURCES 4
 #define GD_ADJ_SHIFT 26                    // bond adjacency entry = partner | type << 26 (| GD_ADJ_LOCAL)
 #define GD_ADJ_MASK ((1u << GD_ADJ_SHIFT) - 1u)
