@@ -121,6 +121,7 @@ struct gd_system {
     DevBuf<float4> pos[2], xb, fout, snap;
     DevBuf<unsigned> orig[2], slot_of, cell_id, rank, cell_cnt, cell_start, nbr, meta, badj, flags, cell_s;
     DevBuf<unsigned short> nbr16; DevBuf<TileDesc> tiles;
+    DevBuf<float4> rec_x0; DevBuf<uint2> rec_mo; DevBuf<unsigned char> len_prev;
     DevBuf<float> bbox;
     DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<int4> chain;
     float mob_uniform = -1.f;
@@ -177,7 +178,8 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->react_part.resize((size_t)s->R * s->nblk) == hipSuccess && s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->lcount_d.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
-         s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess;
+         s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
+         s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess;
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
     gd_launch_identity(s->orig[0].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     if (hipStreamSynchronize(s->stream) != hipSuccess) { delete s; return fail(GD_EHIP, "gd_create: identity kernel failed"); }
@@ -615,7 +617,7 @@ static void fill_common(gd_system *s, StepParams &p)
     p.nbr = s->nbr.p; p.nbr16 = s->nbr16.p; p.tiles = s->tiles.p; p.tiled = s->list_tiled ? 1 : 0; p.packed_ab = s->packed_ab ? 1 : 0;
     p.cpb = s->cpb; p.tile_cap = s->list_tiled ? s->list_tile_cap : s->tile_cap;   // as at the build of the list in use
     p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
-    p.meta = s->meta.p; p.W = s->W; p.badj = s->badj.p; p.chain = s->chain.p;
+    p.meta = s->meta.p; p.rec_x0 = s->rec_x0.p; p.rec_mo = s->rec_mo.p; p.W = s->W; p.badj = s->badj.p; p.chain = s->chain.p;
     p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.react_part = s->react_part.p; p.flags = s->flags.p;
     if (s->has_pair) {
         const gd_pair_softcore &q = s->pair;
@@ -682,7 +684,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.ab = s->ab.p; b.mob = s->mobs.p; b.bendE = s->bendE.p; b.badj = s->badj.p; b.has_bend = s->has_bend ? 1 : 0;
     b.mob_is_uniform = s->mob_uniform >= 0.f ? 1 : 0;
     b.chain = s->chain.p; b.nbr = (with_list && !tiled) ? s->nbr.p : nullptr; b.nbr16 = tiled ? s->nbr16.p : nullptr;
-    b.meta = s->meta.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
+    b.meta = s->meta.p; b.rec_x0 = s->rec_x0.p; b.rec_mo = s->rec_mo.p; b.len_prev = s->len_prev.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
     gd_launch_build(b, s->stream);

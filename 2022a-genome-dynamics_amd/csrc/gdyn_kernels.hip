@@ -314,22 +314,31 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
     }
     GD_STAMP(11);     // descriptor + DMA issue
-    const unsigned slot = blk * GD_BLOCK + tid;      // (a per-block permutation balancing the waves by list length bought +4% on
-                                                     // unrelaxed, clumpy systems and nothing on relaxed ones: dropped)
+    // tiled path: the thread's record (written by the build in balanced thread order) names its bead's slot
+    const size_t gt = rbase + blk * GD_BLOCK + tid;
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 mo = make_uint2(0u, 0u);
+    if (TILED) { rec = p.rec_x0[gt]; mo = p.rec_mo[gt]; }
+    const unsigned slot = TILED ? (__float_as_uint(rec.w) == 0xffffu ? p.N : blk * GD_BLOCK + __float_as_uint(rec.w)) : blk * GD_BLOCK + tid;
     const bool valid = slot < p.N;
     const size_t g = rbase + slot;
     const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
-    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(g >> 6) * NCL * 64 + (g & 63);
-    const uint4 *__restrict__ adj = (const uint4 *)p.badj + (size_t)(g >> 6) * NCB * 64 + (g & 63);
+    const size_t gl = TILED ? gt : g;        // lists, adjacency chunks: thread order on the tiled path
+    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(gl >> 6) * NCL * 64 + (gl & 63);
+    const uint4 *__restrict__ adj = (const uint4 *)p.badj + (size_t)(gl >> 6) * NCB * 64 + (gl & 63);
     float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f), x0 = xi4;
     unsigned meta = 0, oid = 0;
     uint4 adj0 = make_uint4(0, 0, 0, 0), qa = adj0, qb = adj0;
     float mu = p.mob_uniform;
     if (valid) {
         xi4 = p.pos_in[g];
-        meta = p.meta[g];
-        if (MODE != GD_MODE_ENERGY) oid = p.orig[g];
-        if (MODE == GD_MODE_STEP) { x0 = p.xb[g]; if (p.mob_uniform < 0.f) mu = p.mob[g]; }
+        if (TILED) { meta = mo.x; oid = mo.y; x0 = rec; }
+        else {
+            meta = p.meta[g];
+            if (MODE != GD_MODE_ENERGY) oid = p.orig[g];
+            if (MODE == GD_MODE_STEP) x0 = p.xb[g];
+        }
+        if (MODE == GD_MODE_STEP && p.mob_uniform < 0.f) mu = p.mob[g];
         if (p.has_bonds) adj0 = adj[0];
         // list chunks are read once per step and never reused: non-temporal, so they do not displace the tiles'
         // halo lines (which neighbouring blocks re-read) from the XCD's L2
@@ -1068,8 +1077,28 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
-    const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
+    const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t rbase = (size_t)r * p.Np;
+    // Tiled path: k_step's THREADS are ordered by the list length their bead had at the previous build (a very good
+    // predictor of the new one), longest first, so that the 64 lanes of a k_step wave run the same number of list
+    // batches.  This kernel still works slot by slot (neighbouring slots share their row windows: broadcast LDS reads, equal
+    // trip counts), but writes each bead's list, adjacency chunks and record at the position gt of the k_step thread
+    // that will own it.
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x;
+    size_t gt = rbase + slot;
+    if (TILED) {
+        __shared__ unsigned s_hist[32], s_off[32];
+        if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned bin = 31u;                                        // slots past N: last
+        if (slot < p.N) bin = 30u - min((unsigned)p.len_prev[(size_t)r * p.N + p.orig_out[rbase + slot]], 30u);
+        const unsigned rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned run = 0; for (int b = 0; b < 32; b++) { s_off[b] = run; run += s_hist[b]; } }
+        __syncthreads();
+        gt = rbase + blk * GD_BLOCK + s_off[bin] + rank;
+    }
+    const size_t g = rbase + slot;
     const float4 *__restrict__ rpos = p.pos_out + rbase;
     // block-uniform descriptor, read through a uniform pointer (scalar loads; a local copy indexed in
     // loops would be demoted to scratch memory)
@@ -1113,7 +1142,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             return false;
         };
         const unsigned deg = (GD_ABL == 3 || GD_ABL == 4) ? 0u : p.bdeg_o[o];
-        uint4 *__restrict__ adjw = (uint4 *)p.badj + (size_t)(g >> 6) * (p.WB / 4) * 64 + (g & 63);
+        const size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
+        uint4 *__restrict__ adjw = (uint4 *)p.badj + (size_t)(gw >> 6) * (p.WB / 4) * 64 + (gw & 63);
         // one 16-byte adjacency chunk per round: its four gathers (entry by bead, then slot by partner) are in flight
         // together and the chunk is written with one store
         for (unsigned k0 = 0; k0 < deg; k0 += 4) {
@@ -1154,7 +1184,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // reads (8 x u16 tiled, 4 x u32 generic); a bead's 8 (4) consecutive entries share one chunk.
             constexpr unsigned PER = TILED ? 8u : 4u;
             const unsigned NC = p.W / PER;
-            uint4 *__restrict__ lst = (TILED ? (uint4 *)p.nbr16 : (uint4 *)p.nbr) + (size_t)(g >> 6) * NC * 64 + (g & 63);
+            uint4 *__restrict__ lst = (TILED ? (uint4 *)p.nbr16 : (uint4 *)p.nbr) + (size_t)(gw >> 6) * NC * 64 + (gw & 63);
             // the 16-byte chunk under construction lives in four registers (an LDS staging slot per thread would cost
             // the 8 KB that separate two from three resident blocks per CU); every PER-th entry the finished chunk
             // goes out as one 16-byte global store (2-byte scattered global stores were 25% of the build)
@@ -1326,8 +1356,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             flush();
             cnt = found;
         }
-        p.meta[g] = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
+        const unsigned meta = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
+        if (TILED) {
+            const float4 xb = rpos[slot];
+            p.rec_x0[gt] = make_float4(xb.x, xb.y, xb.z, __uint_as_float(slot - blk * GD_BLOCK));
+            p.rec_mo[gt] = make_uint2(meta, o);
+            p.len_prev[(size_t)r * p.N + o] = (unsigned char)min((listlen + GD_UNROLL - 1u) / GD_UNROLL, 30u);
+        } else p.meta[g] = meta;
     }
+    if (TILED && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, 0u); }
     GD_FSTAMP(5);     // padding, meta
     unsigned long long c64 = min(cnt, p.W);
     for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o, 64);

@@ -129,6 +129,10 @@ struct StepParams {
     int packed_ab;                      // 1: pos.w holds (a,b) as two fp16 (exactly representable)
     unsigned cpb;                       // blocks per replica per XCD (XCD-aware block mapping)
     unsigned tile_cap;                  // beads of LDS per block
+    // tiled path: per-THREAD records written by the build (threads of a block are ordered by list length so that the
+    // lanes of a wave run the same number of list batches): build position + block-local slot, meta + bead id
+    const float4 *rec_x0;
+    const uint2 *rec_mo;
     int has_softcore_bonds;             // some bond set is a soft core (the glue pairs of the 1 kb model): rare path
     const unsigned *badj;               // chunked like the pair lists, 4 entries per chunk
     const int4 *chain;                  // slots of (i-2, i-1, i+1, i+2) or -1
@@ -202,6 +206,8 @@ struct BuildParams {
     unsigned cpb, tile_cap;
     unsigned *flags;
     unsigned long long *lcount;         // [R] directed list entries
+    float4 *rec_x0; uint2 *rec_mo;      // per-thread records of the tiled path (see StepParams)
+    unsigned char *len_prev;            // [R*N] by bead id: list batches at the previous build (the balancing sort key)
     unsigned long long *dbg;            // section stamps of timing-only builds (the force-output buffer)
 };
 
