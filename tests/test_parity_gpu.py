@@ -355,3 +355,28 @@ def _without_softwell_forces(s, tg):
     f = s.forces()
     s.set_pair_softwell(0.8, 0.2, 0.4, tg)
     return f
+
+
+def test_equilibrium_statistics_match_oracle(hip, oracle):
+    """Trajectories diverge (chaos), statistics must not: 6000 steps of the 2000-bead interphase model at T = 1 on the device
+    (fp32, list cadence, rollbacks) and in the oracle (fp64); time averages over the second half agree within their noise."""
+    out = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        s, info = wl.genome_interphase(lib, n_beads=2000)
+        s.begin_phase()
+        s.run(3000, 1e-5, 1.0, seed=SEED + 5, flags=g.RUN_WALL_DYNAMICS)
+        e, bond, rg = [], [], []
+        for k in range(30):
+            s.run(100, 1e-5, 1.0, seed=SEED + 5, flags=g.RUN_WALL_DYNAMICS)
+            x = s.positions()[0]
+            e.append(float(s.energy()[0]) / 2000)
+            d = np.linalg.norm(np.diff(x, axis=0), axis=1)
+            bond.append(np.median(d))                       # chain bonds dominate the median (few inter-chain jumps)
+            rg.append(np.sqrt(((x - x.mean(axis=0)) ** 2).sum(axis=1).mean()))
+        out[name] = (np.mean(e), np.std(e), np.mean(bond), np.mean(rg), np.array(s.context().semiaxes))
+    eh, sh_, bh, rh, ah = out["hip"]
+    eo, so_, bo, ro, ao = out["oracle"]
+    assert abs(eh - eo) <= 5 * max(sh_, so_) / np.sqrt(30) + 0.01 * abs(eo)
+    assert bh == pytest.approx(bo, rel=0.02)
+    assert rh == pytest.approx(ro, rel=0.01)
+    assert np.allclose(ah, ao, rtol=2e-3)                   # the wall ODE integrates the same mean reaction
