@@ -1,16 +1,19 @@
 // gdyn_kernels.hip -- hand-written HIP kernels (gfx950, wave64) of the Brownian-dynamics path.
 //
-//   k_step<MODE,PERIODIC>  one thread per bead slot: neighbour-list pair forces (AB-mixed
-//                          soft cores), bonded / bending / point-source / ellipsoid-wall forces,
-//                          Euler-Maruyama update with Philox4x32-10 noise, Verlet-skin check,
-//                          per-block wall-reaction partials.  The per-step "callback" state
-//                          (time, bead/bond scale, wall semiaxes ODE; reference
-//                          5-sim-genome/src/simulation_interphase/simulation_driver_interphase.cc:12-80)
-//                          is advanced by wave 0 of every block in the prologue of the NEXT
-//                          launch, so a run of steps needs no host round trip.
+//   k_step<MODE,PERIODIC,TILED,PK,S16>
+//                          one thread per bead: neighbour-list pair forces (AB-mixed soft cores), bonded / bending /
+//                          point-source / ellipsoid- and inner-sphere-wall forces, Euler-Maruyama update with
+//                          Philox4x32-10 noise, Verlet-skin check, per-block wall-reaction partials.  TILED: the block's
+//                          beads and their neighbour cells are staged into LDS by DMA and list entries address that
+//                          tile.  The per-step "callback" state (time, bead/bond scale, wall semiaxes ODE; reference
+//                          5-sim-genome/src/simulation_interphase/simulation_driver_interphase.cc:12-80) is advanced
+//                          by wave 0 of every block in the prologue of the NEXT launch: no host round trip per step.
+//   k_softwell             droplet attraction among the few hundred target beads (after k_step; linear in the force).
 //   k_bbox .. k_fill       neighbour search (micromd md::neighbor_searcher; call sites e.g.
-//                          simulation_interphase/contact_map.cc:64-66): bounding box, cell
-//                          binning, counting sort into slot order, ELL Verlet list fill.
+//                          simulation_interphase/contact_map.cc:64-66): bounding box, cell binning, counting sort into
+//                          slot order, tile descriptors, list fill (27-cell sweep from the LDS tile, or from global
+//                          memory on the generic path).
+//   GD_ABL                 timing-only builds (tools/abl.sh): term ablations 11-15, section stamps 30 / 34.
 //
 // MFMA is not used: the path is an irregular short-range N-body sum.
 #include <hip/hip_fp16.h>
@@ -18,7 +21,8 @@
 #include "gdyn_types.h"
 
 #ifndef GD_ABL
-#define GD_ABL 0   // timing-only ablation builds (never shipped): 1 = no list stores, 2 = no sweep, 3 = no sweep + no bond re-map, 4 = 3 + no tile staging
+#define GD_ABL 0   // timing-only builds (never shipped): 2 = no sweep, 3 = 2 + no bond re-map, 4 = 3 + no tile staging, 11-15 = one force
+                   // term removed, 30 / 34 = in-kernel section stamps of k_step / k_fill
 #endif
 
 #define TERM_PAIR 1u
