@@ -76,7 +76,7 @@ class _RunDesc(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("skin", C.c_double), ("rebuild_interval", C.c_uint32), ("adapt_interval", C.c_uint32),
-                ("list_width", C.c_uint32), ("use_graph", C.c_uint32), ("kernel_path", C.c_uint32)]
+                ("list_width", C.c_uint32), ("kernel_path", C.c_uint32)]
 
 
 class Timing(C.Structure):
@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "gd_add_bond_pairs", "gd_set_dynamic_pairs", "gd_add_bending_range", "gd_add_point_source",
     "gd_set_ellipsoid_wall", "gd_set_inner_sphere_wall", "gd_set_pair_softwell", "gd_set_scaling", "gd_get_context", "gd_begin_phase", "gd_set_context",
     "gd_run", "gd_compute_energy", "gd_compute_forces", "gd_search_pairs", "gd_set_tuning",
-    "gd_get_timing", "gd_get_stream", "gd_debug_bench",
+    "gd_get_timing", "gd_get_stream",
 ]
 
 
@@ -152,7 +152,6 @@ class Lib:
         d.gd_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
         d.gd_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         d.gd_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-        d.gd_debug_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
 
     @property
     def backend(self):
@@ -334,8 +333,8 @@ class System:
             self.lib.check(self.lib.dll.gd_search_pairs(self._h, replica, dcut, _uptr(out), n.value, C.byref(n)))
         return out
 
-    def set_tuning(self, skin=0.0, rebuild_interval=0, adapt_interval=1, list_width=0, use_graph=1, kernel_path=0):
-        t = Tuning(skin, rebuild_interval, adapt_interval, list_width, use_graph, kernel_path)
+    def set_tuning(self, skin=0.0, rebuild_interval=0, adapt_interval=1, list_width=0, kernel_path=0):
+        t = Tuning(skin, rebuild_interval, adapt_interval, list_width, kernel_path)
         self.lib.check(self.lib.dll.gd_set_tuning(self._h, C.byref(t)))
 
     def timing(self):
@@ -344,8 +343,13 @@ class System:
         return t
 
     def debug_bench(self, what, n=20):
+        """Developer builds only (csrc/gdyn_dev.h, libgdyn_dev.so): kernel micro-benchmark on the current state."""
+        f = getattr(self.lib.dll, "gd_debug_bench", None)
+        if f is None:
+            raise GdynError(6, "gd_debug_bench: not in this library (developer builds only: make -C csrc dev, GDYN_LIB=libgdyn_dev.so)")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         ms = C.c_double(0)
-        self.lib.check(self.lib.dll.gd_debug_bench(self._h, what, n, C.byref(ms)))
+        self.lib.check(f(self._h, what, n, C.byref(ms)))
         return ms.value
 
     def stream(self):

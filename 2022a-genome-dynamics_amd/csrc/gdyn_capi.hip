@@ -19,6 +19,9 @@
 #include <hip/hip_fp16.h>
 
 #include "gdyn_types.h"
+#ifdef GD_DEV
+#include "gdyn_dev.h"
+#endif
 
 // ------------------------------------------------------------------ errors
 
@@ -43,6 +46,14 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *gd_last_error(void) { return g_err; }
+
+// Experiment hooks (environment variables, debug prints, the kernel micro-benchmark) exist in developer builds only
+// (make dev -> libgdyn_dev.so, -DGD_DEV); the product library reads no environment variable.
+#ifdef GD_DEV
+static const char *dev_env(const char *name) { return getenv(name); }
+#else
+static const char *dev_env(const char *) { return nullptr; }
+#endif
 extern "C" const char *gd_backend_name(void) { return "hip"; }
 
 template <typename T>
@@ -105,7 +116,7 @@ struct gd_system {
 
     // tuning / cadence
     double skin = 0.75;   // relative to the pair cutoff; 0.65..0.8 are within 3% of each other on S-genome-30k, smaller tiles leave more LDS margin
-    uint32_t K = 4, adapt = 1, use_graph = 0;
+    uint32_t K = 4, adapt = 1;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
     float rv = 0;
@@ -125,7 +136,7 @@ struct gd_system {
     DevBuf<float> bbox;
     DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<int4> chain;
     float mob_uniform = -1.f;
-    DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part; DevBuf<double> epart;
+    DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part[2]; DevBuf<double> epart;   // react_part ping-pongs with ctx
     DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
     int ocur = 0;   // which orig[] buffer is current
     std::vector<hipEvent_t> events;
@@ -158,7 +169,7 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     s->nblk = (s->N + GD_BLOCK - 1) / GD_BLOCK;
     s->Np = s->nblk * GD_BLOCK;
     s->cpb = (s->nblk + GD_XCDS - 1) / GD_XCDS;
-    if (s->R % GD_XCDS == 0 && !getenv("GDYN_SLICE_MAP")) s->cpb = 0;      // whole replicas per XCD (see block_map)
+    if (s->R % GD_XCDS == 0 && !dev_env("GDYN_SLICE_MAP")) s->cpb = 0;      // whole replicas per XCD (see block_map)
     s->a.assign(s->N, 0.0); s->b.assign(s->N, 0.0); s->mob.assign(s->N, 1.0); s->bend.assign(s->N, 0.0);
     s->hctx.assign(s->R, DevCtx{});
     for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; }   // wall_semiaxes {0,0,0} until a wall is set (simulation_context.hpp:16)
@@ -169,14 +180,15 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     const size_t RNp = (size_t)s->R * s->Np, RN = (size_t)s->R * s->N;
     bool ok = true;
     for (int k = 0; k < 2; k++) {
-        ok = ok && s->pos[k].resize(RNp) == hipSuccess && s->orig[k].resize(RNp) == hipSuccess && s->ctx[k].resize(s->R) == hipSuccess;
+        ok = ok && s->pos[k].resize(RNp) == hipSuccess && s->orig[k].resize(RNp) == hipSuccess && s->ctx[k].resize(s->R) == hipSuccess &&
+             s->react_part[k].resize((size_t)s->R * s->nblk) == hipSuccess;
     }
     ok = ok && s->xb.resize(RNp) == hipSuccess && s->slot_of.resize(RN) == hipSuccess && s->cell_id.resize(RNp) == hipSuccess &&
          s->rank.resize(RNp) == hipSuccess && s->cell_cnt.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess &&
          s->cell_start.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess && s->meta.resize(RNp) == hipSuccess &&
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
-         s->react_part.resize((size_t)s->R * s->nblk) == hipSuccess && s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
+         s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->lcount_d.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess;
@@ -388,6 +400,11 @@ extern "C" int gd_set_pair_softwell(gd_system *s, double energy, double decay, d
     if (n > 4096) return fail(GD_EINVAL, "gd_set_pair_softwell: at most 4096 targets");
     if (n && (!(decay > 0) || !(cutoff > 0))) return fail(GD_EINVAL, "gd_set_pair_softwell: decay and cutoff must be positive");
     for (uint32_t k = 0; k < n; k++) if (targets[k] >= s->N) return fail(GD_EINVAL, "gd_set_pair_softwell: target %u out of range", k);
+    {   // set_neighbor_targets takes a set of particles: a repeated index would make two threads update one bead
+        std::vector<uint32_t> t(targets, targets + n);
+        std::sort(t.begin(), t.end());
+        for (uint32_t k = 1; k < n; k++) if (t[k] == t[k - 1]) return fail(GD_EINVAL, "gd_set_pair_softwell: target %u listed twice", t[k]);
+    }
     HIPCHK(hipSetDevice(s->device));
     s->sw_n = 0;
     if (n) {
@@ -477,8 +494,7 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (t->skin > 0) s->skin = t->skin;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
     s->adapt = t->adapt_interval;
-    if (t->list_width > 0 && t->list_width != s->W) { s->W = 0; s->nbr.resize(0); s->W = t->list_width; }
-    s->use_graph = t->use_graph;
+    if (t->list_width > 0 && t->list_width != s->W) { (void)s->nbr.resize(0); s->W = t->list_width; }
     if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0, 1 or 2");
     s->kernel_path = t->kernel_path; s->tiled_ok = true;
     s->list_valid = false;
@@ -618,7 +634,10 @@ static void fill_common(gd_system *s, StepParams &p)
     p.cpb = s->cpb; p.tile_cap = s->list_tiled ? s->list_tile_cap : s->tile_cap;   // as at the build of the list in use
     p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
     p.meta = s->meta.p; p.rec_x0 = s->rec_x0.p; p.rec_mo = s->rec_mo.p; p.W = s->W; p.badj = s->badj.p; p.chain = s->chain.p;
-    p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.react_part = s->react_part.p; p.flags = s->flags.p;
+    p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.flags = s->flags.p;
+    // wall-reaction partials ping-pong with the context: a launch reads the previous step's partials while its blocks
+    // write this step's (one buffer would let late blocks read a mix of two steps)
+    p.react_in = s->react_part[s->ccur].p; p.react_out = s->react_part[s->ccur ^ 1].p;
     if (s->has_pair) {
         const gd_pair_softcore &q = s->pair;
         p.pair = PairP{(float)q.eps_a, (float)q.sigma_a, (float)q.eps_b, (float)q.sigma_b, q.p_a, q.q_a, q.p_b, q.q_b,
@@ -713,7 +732,7 @@ static unsigned pick_tile_cap(unsigned need)
     static std::vector<unsigned> caps = {3312u, 5072u, 8192u};
     static bool init = false;
     if (!init) {      // experiment hook: GDYN_TILE_CAPS=a,b,c
-        if (const char *e = getenv("GDYN_TILE_CAPS")) { caps.clear(); for (const char *q = e; *q;) { caps.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
+        if (const char *e = dev_env("GDYN_TILE_CAPS")) { caps.clear(); for (const char *q = e; *q;) { caps.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
         init = true;
     }
     for (unsigned c : caps) if (need <= c) return c;
@@ -739,7 +758,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
         if (s->box_kind == GD_BOX_PERIODIC && want > 5072u) s->tiled_ok = false;      // (see the overflow branch below)
         else if (want != s->tile_cap && want <= 8192u) {
-            if (getenv("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
+            if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
         }
     }
@@ -752,14 +771,14 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         else s->tiled_ok = false;                // too dense for one tile: generic path
     }
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
-    if (tover && getenv("GDYN_DEBUG")) {
+    if (tover && dev_env("GDYN_DEBUG")) {
         std::vector<GridP> gp(s->R);
         (void)hipMemcpy(gp.data(), s->grid.p, s->R * sizeof(GridP), hipMemcpyDeviceToHost);
         for (uint32_t r = 0; r < std::min(s->R, 3u); r++)
             fprintf(stderr, "[gdyn] grid r%u: nc %d %d %d ncell %d org %g %g %g inv %g flags need_t %u\n", r, gp[r].nc[0], gp[r].nc[1], gp[r].nc[2],
                     gp[r].ncell, gp[r].org[0], gp[r].org[1], gp[r].org[2], gp[r].inv[0], f[r * GD_NFLAGS + GD_FLAG_NEED_TILE]);
     }
-    if ((over || tover) && getenv("GDYN_DEBUG"))
+    if ((over || tover) && dev_env("GDYN_DEBUG"))
         fprintf(stderr, "[gdyn] overflow: list %d (need %u -> W %u), tile %d (need %u -> cap %u, tiled_ok %d)\n", (int)over, need_w, s->W,
                 (int)tover, need_t, s->tile_cap, (int)s->tiled_ok);
     return over || tover;
@@ -855,7 +874,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         hipEvent_t ev_begin = get_event(s, nev++);
         HIPCHK(hipEventRecord(ev_begin, s->stream));
         int64_t k = 0;
-        uint64_t visited = 0;
+        bool full_interval = false;      // the chunk contains the last step of a complete K-step interval
         while (k < chunk) {
             if (!s->list_valid || s->steps_since_build >= s->K) {
                 hipEvent_t e0 = get_event(s, nev++), e1 = get_event(s, nev++);
@@ -873,7 +892,10 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 p.dt_d = run->timestep; p.dt = (float)run->timestep; p.kT = (float)run->temperature; p.seed = run->seed;
                 p.noise_mode = run->noise_mode; p.run_flags = run->flags;
                 p.host_noise = host_noise ? s->noise.p + (size_t)(done + k + q) * RN * 3 : nullptr;
-                p.record_disp = (q == n - 1);
+                // the interval adaptation needs the displacement at K steps since the build: recorded at the last force
+                // evaluation of a COMPLETE interval only (a chunk that ends mid-interval records nothing and adapts nothing)
+                p.record_disp = (s->steps_since_build + (uint32_t)q + 1u == s->K);
+                full_interval |= p.record_disp != 0;
                 gd_launch_step(p, GD_MODE_STEP, s->stream);
                 if (s->sw_n) launch_softwell(s, p, 0);
                 s->pcur ^= 1; s->ccur ^= 1;
@@ -883,7 +905,6 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             s->timing.step_launches += (uint64_t)n;
             s->steps_since_build += (uint32_t)n;
             k += n;
-            (void)visited;
         }
         // apply the callback of the last step, then check the chunk
         fill_common(s, p);
@@ -931,7 +952,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         unsigned long long L = 0;
         for (auto v : s->lcount) L += v;
         s->timing.list_entries_visited += L * (uint64_t)chunk;   // L of the last build, per step
-        if (s->adapt && with_list) {
+        if (s->adapt && with_list && full_interval) {
             const double cut_now = pair_cutoff(s) * (s->pair.scale_by_bead_scale ? bead_scale_bound(s, nullptr, 0) : 1.0);
             const double lim = 0.5 * (s->rv - cut_now), d = std::sqrt((double)maxd2);
             if (lim > 0 && d > 0) {
@@ -939,7 +960,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 // fluctuates by only ~3.5% between intervals (sigma / sqrt(2 ln n)), so 15% is a 4-sigma margin; a violation
                 // costs one rolled-back chunk and is remembered (K_bad)
                 const double ratio = d / lim;
-                static const double target = getenv("GDYN_K_TARGET") ? atof(getenv("GDYN_K_TARGET")) : 0.85;
+                static const double target = dev_env("GDYN_K_TARGET") ? atof(dev_env("GDYN_K_TARGET")) : 0.85;
                 double knew = (double)s->K * (target / ratio) * (target / ratio);
                 knew = std::min(knew, 2.0 * s->K + 1);
                 s->K = (uint32_t)std::max(1.0, std::min(200.0, std::floor(knew)));
@@ -988,10 +1009,10 @@ extern "C" int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
     StepParams p;
     fill_common(s, p);
     p.term_mask = mask;
-    HIPCHK(hipMemsetAsync(s->react_part.p, 0, s->react_part.n * sizeof(float4), s->stream));
+    HIPCHK(hipMemsetAsync(p.react_out, 0, s->react_part[0].n * sizeof(float4), s->stream));
     gd_launch_step(p, GD_MODE_FORCE, s->stream);
     if (s->sw_n && (mask & GD_TERM_PAIR)) launch_softwell(s, p, 1);
-    if (s->has_wall) { gd_launch_finalize(p, 1, s->stream); s->ccur ^= 1; }
+    if (s->has_wall) { p.react_in = p.react_out; gd_launch_finalize(p, 1, s->stream); s->ccur ^= 1; }
     const size_t RN = (size_t)s->R * s->N;
     std::vector<float4> h(RN);
     HIPCHK(hipMemcpyAsync(h.data(), s->fout.p, RN * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
@@ -1029,8 +1050,8 @@ extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *
     return GD_OK;
 }
 
-// ------------------------------------------------------------ micro-benchmark
-
+// ------------------------------------------------------------ micro-benchmark (developer builds only)
+#ifdef GD_DEV
 extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
 {
     if (!s || !mean_ms || n < 1) return fail(GD_EINVAL, "gd_debug_bench: bad argument");
@@ -1070,3 +1091,4 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
     GDCHK(clear_flags(s));
     return GD_OK;
 }
+#endif

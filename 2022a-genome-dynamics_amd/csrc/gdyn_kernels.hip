@@ -221,7 +221,7 @@ __device__ __forceinline__ void apply_callback(DevCtx &c, const StepParams &p, u
     double rx = 0, ry = 0, rz = 0;
     if (p.wall.enabled) {
         for (unsigned b = lane; b < p.nblk; b += 64) {
-            const float4 v = p.react_part[(size_t)r * p.nblk + b];
+            const float4 v = p.react_in[(size_t)r * p.nblk + b];
             rx += v.x; ry += v.y; rz += v.z;
         }
         rx = wave_sum_d(rx); ry = wave_sum_d(ry); rz = wave_sum_d(rz);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         if (tid == 0) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int w = 0; w < GD_BLOCK / 64; w++) { v.x += s_red[w][0]; v.y += s_red[w][1]; v.z += s_red[w][2]; }
-            p.react_part[(size_t)r * p.nblk + blk] = v;
+            p.react_out[(size_t)r * p.nblk + blk] = v;
         }
     }
     if (MODE == GD_MODE_ENERGY) {
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64) void k_finalize(const StepParams p, int reduce_
     if (reduce_only) {
         double rx = 0, ry = 0, rz = 0;
         for (unsigned b = lane; b < p.nblk; b += 64) {
-            const float4 v = p.react_part[(size_t)r * p.nblk + b];
+            const float4 v = p.react_in[(size_t)r * p.nblk + b];
             rx += v.x; ry += v.y; rz += v.z;
         }
         c.react[0] = wave_sum_d(rx); c.react[1] = wave_sum_d(ry); c.react[2] = wave_sum_d(rz);

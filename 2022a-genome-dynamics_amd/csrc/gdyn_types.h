@@ -139,7 +139,8 @@ struct StepParams {
     // context
     const DevCtx *ctx_in;
     DevCtx *ctx_out;
-    float4 *react_part;                 // [R][nblk]
+    const float4 *react_in;             // [R][nblk] wall-reaction partials of the previous step (read by the callback)
+    float4 *react_out;                  // [R][nblk] this step's partials (double-buffered with the context)
     unsigned *flags;
     // model
     PairP pair;

@@ -274,11 +274,11 @@ int gd_search_pairs(gd_system *sys, uint32_t replica, double dcut,
 /* --------------------------------------------------------- tuning / timing */
 
 typedef struct {
-    double   skin;              /* Verlet skin as a fraction of the cutoff (default 0.5) */
+    double   skin;              /* Verlet skin as a fraction of the cutoff: list radius = cutoff * (1 + skin); 0 keeps the
+                                   current value (default 0.75) */
     uint32_t rebuild_interval;  /* initial steps between list builds; 0 = auto */
     uint32_t adapt_interval;    /* 1 = adapt interval from measured displacements */
     uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
-    uint32_t use_graph;         /* replay steps from a hipGraph */
     uint32_t kernel_path;       /* 0 auto, 1 generic (global-gather lists), 2 LDS-tiled (open box, fp16-exact a/b) */
 } gd_tuning;
 
@@ -293,10 +293,6 @@ typedef struct {
 } gd_timing;
 
 int gd_get_timing(gd_system *sys, gd_timing *out);
-/* Developer micro-benchmark (not part of the reference's interface): times `n` back-to-back launches of
- * one piece of the path on the CURRENT state with HIP events, without advancing the trajectory.
- * what = 0: full neighbour-list build; 1: step kernel (output discarded). Returns mean ms per launch. */
-int gd_debug_bench(gd_system *sys, int what, int n, double *mean_ms);
 /* Stream the handle enqueues on (hipStream_t as void*), for callers' own events. */
 int gd_get_stream(gd_system *sys, void **stream);
 

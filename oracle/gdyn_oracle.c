@@ -433,6 +433,9 @@ int gd_set_pair_softwell(gd_system *s, double energy, double decay, double cutof
     if (n > 4096) return fail(GD_EINVAL, "gd_set_pair_softwell: at most 4096 targets");
     if (n && (!(decay > 0) || !(cutoff > 0))) return fail(GD_EINVAL, "gd_set_pair_softwell: decay and cutoff must be positive");
     for (uint32_t k = 0; k < n; k++) if (targets[k] >= s->N) return fail(GD_EINVAL, "gd_set_pair_softwell: target %u out of range", k);
+    /* set_neighbor_targets takes a set of particles: a repeated index would count its pairs twice */
+    for (uint32_t k = 1; k < n; k++) for (uint32_t q = 0; q < k; q++)
+        if (targets[q] == targets[k]) return fail(GD_EINVAL, "gd_set_pair_softwell: target %u listed twice", targets[k]);
     free(s->sw_targets); s->sw_targets = NULL; s->sw_n = 0;
     if (n) {
         s->sw_targets = malloc(n * sizeof(uint32_t));
@@ -519,7 +522,6 @@ int gd_set_tuning(gd_system *s, const gd_tuning *t)
     return GD_OK;
 }
 int gd_get_timing(gd_system *s, gd_timing *o) { if (!s || !o) return fail(GD_EINVAL, "gd_get_timing: NULL"); *o = s->timing; return GD_OK; }
-int gd_debug_bench(gd_system *s, int what, int n, double *ms) { (void)s; (void)what; (void)n; (void)ms; return fail(GD_EUNSUPPORTED, "gd_debug_bench: device-only"); }
 int gd_get_stream(gd_system *s, void **st) { (void)s; if (st) *st = NULL; return GD_OK; }
 
 /* --------------------------------------------------------------- cell grid */

@@ -173,6 +173,30 @@ def test_rollback_is_transparent(hip):
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-4
 
 
+def test_short_runs_do_not_inflate_the_rebuild_interval(hip):
+    """The callers' cadence (simulation_driver_interphase.cc:12-44: chunks that end at the next logging / sampling
+    step; bench.py --warmup 5 --steps 20): runs shorter than one rebuild interval measure the displacement of a
+    PARTIAL interval and must not be used to lengthen the interval -- the next long run would violate the skin
+    and be rolled back."""
+    s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=8)
+    dt, kT = info["timestep"], info["temperature"]
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    s.begin_phase()
+    s.run(400, dt, kT, seed=SEED, flags=flags)           # lets the interval adapt on complete intervals
+    c0 = s.context()
+    k_verified = c0.rebuild_interval
+    assert k_verified >= 4
+    s.begin_phase()                                      # invalidates the list, like the bench's begin_phase
+    s.run(5, dt, kT, seed=SEED, flags=flags)
+    assert s.context().rebuild_interval == k_verified    # 5 < K steps: no complete interval, no adaptation
+    s.run(20, dt, kT, seed=SEED, flags=flags)
+    for _ in range(10):
+        s.run(1, dt, kT, seed=SEED, flags=flags)
+    c1 = s.context()
+    assert c1.rollbacks == c0.rollbacks, (c0.rollbacks, c1.rollbacks)
+    assert c1.rebuild_interval <= int(1.3 * k_verified) + 1, (k_verified, c1.rebuild_interval)
+
+
 # ---------------------------------------------------------------- BASELINE sizes
 
 def test_full_size_genome_properties(hip):
