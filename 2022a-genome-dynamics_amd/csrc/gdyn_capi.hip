@@ -102,6 +102,9 @@ struct gd_system {
     bool topo_dirty = true, list_valid = false, ctx_dirty = true;
     bool has_bend = false, has_bonds = false;
     uint32_t WB = 0, W = 0, ncell_cap = 0;
+    uint32_t list_W = 0;           // row width the list in use was built with (W may change for the next build)
+    uint32_t tiled_off = 0;        // why the tiled path is off: 0 on, 1 a tile overflowed (dense transient: retried later), 2 by design
+    uint32_t tiled_wait = 0, tiled_backoff = 8;     // accepted chunks since / until the next retry of the tiled path
     int pcur = 0, ccur = 0;
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
@@ -496,7 +499,7 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     s->adapt = t->adapt_interval;
     if (t->list_width > 0 && t->list_width != s->W) { (void)s->nbr.resize(0); s->W = t->list_width; }
     if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0, 1 or 2");
-    s->kernel_path = t->kernel_path; s->tiled_ok = true;
+    s->kernel_path = t->kernel_path; s->tiled_ok = true; s->tiled_off = 0;
     s->list_valid = false;
     return GD_OK;
 }
@@ -633,7 +636,7 @@ static void fill_common(gd_system *s, StepParams &p)
     p.nbr = s->nbr.p; p.nbr16 = s->nbr16.p; p.tiles = s->tiles.p; p.tiled = s->list_tiled ? 1 : 0; p.packed_ab = s->packed_ab ? 1 : 0;
     p.cpb = s->cpb; p.tile_cap = s->list_tiled ? s->list_tile_cap : s->tile_cap;   // as at the build of the list in use
     p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
-    p.meta = s->meta.p; p.rec_x0 = s->rec_x0.p; p.rec_mo = s->rec_mo.p; p.W = s->W; p.badj = s->badj.p; p.chain = s->chain.p;
+    p.meta = s->meta.p; p.rec_x0 = s->rec_x0.p; p.rec_mo = s->rec_mo.p; p.W = s->list_W; p.badj = s->badj.p; p.chain = s->chain.p;
     p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.flags = s->flags.p;
     // wall-reaction partials ping-pong with the context: a launch reads the previous step's partials while its blocks
     // write this step's (one buffer would let late blocks read a mix of two steps)
@@ -685,8 +688,10 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
         if (s->W == 0) s->W = 64;
         s->W = (s->W + GD_UNROLL - 1) & ~(GD_UNROLL - 1);
         const size_t need = (size_t)s->W * s->R * s->Np;   // entries; chunked wave-interleaved layout (k_step)
-        if (tiled) { if (s->nbr16.n != need) HIPCHK(s->nbr16.resize(need, false)); }
-        else if (s->nbr.n != need) HIPCHK(s->nbr.resize(need, false));
+        // (grown on demand, given back when a dense transient has passed)
+        if (tiled) { if (s->nbr16.n < need || s->nbr16.n > 4 * need) HIPCHK(s->nbr16.resize(need, false)); }
+        else if (s->nbr.n < need || s->nbr.n > 4 * need) HIPCHK(s->nbr.resize(need, false));
+        s->list_W = s->W;
     }
     BuildParams b;
     memset(&b, 0, sizeof b);
@@ -756,7 +761,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // keeps the larger class for a while, so the margin for the smaller class can be thin)
         unsigned want = pick_tile_cap(need_t + 24);
         if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
-        if (s->box_kind == GD_BOX_PERIODIC && want > 5072u) s->tiled_ok = false;      // (see the overflow branch below)
+        if (s->box_kind == GD_BOX_PERIODIC && want > 5072u) { s->tiled_ok = false; s->tiled_off = 2; }      // (see the overflow branch below)
         else if (want != s->tile_cap && want <= 8192u) {
             if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
@@ -768,9 +773,14 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // image per pair: with one resident block per CU they lose to the generic path (measured on S-1kb-250k)
         const unsigned cap_max = s->box_kind == GD_BOX_PERIODIC ? 5072u : 8192u;
         if (cap <= cap_max) { s->tile_cap = cap; s->tile_hold = 4; }
-        else s->tiled_ok = false;                // too dense for one tile: generic path
+        else { s->tiled_ok = false; s->tiled_off = s->box_kind == GD_BOX_PERIODIC ? 2 : 1; }     // too dense for one tile: generic path
     }
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
+    else if (!tover && need_w > 0) {
+        // the longest list is reported by every build: give the row width back when a dense transient has passed
+        const unsigned want_w = std::max(32u, (need_w + need_w / 4 + 8 + GD_UNROLL - 1) & ~(GD_UNROLL - 1));
+        if (2 * want_w <= s->W) s->W = want_w;       // (takes effect at the next build; the list in use keeps list_W)
+    }
     if (tover && dev_env("GDYN_DEBUG")) {
         std::vector<GridP> gp(s->R);
         (void)hipMemcpy(gp.data(), s->grid.p, s->R * sizeof(GridP), hipMemcpyDeviceToHost);
@@ -940,6 +950,14 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             continue;
         }
         // accepted: timing, context mirror, cadence adaptation
+        if (s->list_tiled) { s->tiled_backoff = 8; s->tiled_wait = 0; }
+        else if (!s->tiled_ok && s->tiled_off == 1 && ++s->tiled_wait >= s->tiled_backoff) {
+            // the tiled path was left because one tile did not fit (a dense transient, e.g. the start of a relaxation):
+            // try it again at the next build, with the largest tile class; a new overflow costs one rolled-back chunk
+            // and doubles the waiting time
+            s->tiled_ok = true; s->tiled_off = 0; s->tiled_wait = 0; s->tiled_backoff = std::min(2 * s->tiled_backoff, 1024u);
+            s->tile_cap = 8192u;
+        }
         float ms = 0;
         for (auto &sp : spans) {
             HIPCHK(hipEventElapsedTime(&ms, s->events[sp.first], s->events[sp.first + 1]));
@@ -1029,7 +1047,7 @@ extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *
     GDCHK(prepare(s));
     GDCHK(build_now(s, (float)dcut, true, false));   // generic (global-slot) list
     s->list_valid = false;   // the force list was overwritten with the search radius
-    const uint32_t N = s->N, W = s->W, NC = W / 4;
+    const uint32_t N = s->N, W = s->list_W, NC = W / 4;
     std::vector<unsigned> cnt(N), org(N);
     HIPCHK(hipMemcpy(cnt.data(), s->meta.p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
     for (auto &c : cnt) c >>= 16;

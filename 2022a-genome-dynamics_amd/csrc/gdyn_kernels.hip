@@ -289,71 +289,96 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     // stay scalar loads; wave 0 also starts its full-context and reaction-partial loads first
     const long long ctx_step0 = p.ctx_in[r].step;
     const int ctx_pending0 = p.ctx_in[r].pending;
-    // ---- prologue, ordered for the in-order vmcnt counter: first everything that does not depend on the thread's
-    // bead (bond table and tile go straight into LDS by DMA, nothing returns to registers), then the per-bead loads;
-    // the noise then waits for the youngest loads only (a static vmcnt).
-    if (TILED && GD_ABL != 12 && (GD_ABL != 33 || (blk & 3u) == 0)) {
-        // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
-        // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
-        // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
+    // ---- prologue (tiled path), ordered for the IN-ORDER vmcnt counter:
+    //   1. the thread's (meta, bead id) record -- the one per-bead value the noise needs -- and the tile descriptor
+    //      (scalar loads: after a DMA the compiler would turn them into per-lane vector loads); both waited for here;
+    //   2. bond table + tile DMAs (straight into LDS, nothing returns to registers);
+    //   3. the other per-bead loads (build position record, first adjacency and list chunks);
+    //   4. the Brownian noise: no wait in front of it, it runs while the DMAs are in flight.
+    // The bead's own position is read from the tile after the barrier (tile index own_base + block-local slot), so no
+    // load depends on another one.
+    const size_t gt = rbase + blk * GD_BLOCK + tid;      // tiled path: the thread's record position (balanced thread order)
+    const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
+    uint2 mo = make_uint2(0u, 0u);
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 adj0 = make_uint4(0, 0, 0, 0), qa = adj0, qb = adj0;
+    unsigned own_base = 0, tile_ok = 0;     // tile_ok == 0: the tile did not fit (flagged by the build; the host rolls the chunk back)
+    if (TILED) {
+        mo = p.rec_mo[gt];
         const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
-        // the whole descriptor is fetched first, with scalar loads: a descriptor read placed after a DMA (which the
-        // compiler must treat as a store) becomes a per-lane vector load behind a full vmcnt(0) wait -- once per range
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = td->len[k]; tst[k] = td->start[k]; tbase[k] = td->base[k]; }
-        if (wid == 0 && lane < 2 * GD_MAX_BOND_TYPES)       // the bond-type table: 32 B per type, 16 B per lane (the buffer always holds the full table)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)p.btab + lane),
-                                             (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
+        own_base = td->own_base; tile_ok = td->nranges;
+        // the record is consumed HERE (an empty asm the compiler has to wait in front of), while it is still the only
+        // vector load in flight: placed behind the DMAs, its wait would be a wait for the whole tile.  Its latency
+        // overlaps the scalar descriptor loads above.
+        asm volatile("" : "+v"(mo.x), "+v"(mo.y));
+        if (GD_ABL != 12 && (GD_ABL != 33 || (blk & 3u) == 0)) {
+            // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
+            // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
+            // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
+            if (wid == 0 && lane < 2 * GD_MAX_BOND_TYPES)       // the bond-type table: 32 B per type, 16 B per lane (the buffer always holds the full table)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)p.btab + lane),
+                                                 (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
 #pragma unroll
-        for (int k = 0; k < GD_TILE_RANGES; k++) {
-            const unsigned len = tlen[k], st = tst[k], base = tbase[k];
-            for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
-                if (q0 + lane < len)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
-                                                     (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
+            for (int k = 0; k < GD_TILE_RANGES; k++) {
+                const unsigned len = tlen[k], st = tst[k], base = tbase[k];
+                for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
+                    if (q0 + lane < len)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
+                                                         (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
+                }
             }
         }
+        GD_STAMP(11);     // record + descriptor + DMA issue
+        // three more loads per thread, unconditionally (every array is allocated for all threads of the block); nothing
+        // before the barrier waits for them
+        rec = p.rec_x0[gt];
+        adj0 = ((const uint4 *)p.badj)[(size_t)(gt >> 6) * NCB * 64 + (gt & 63)];
+        qa = nt_load((const uint4 *)p.nbr16 + (size_t)(gt >> 6) * NCL * 64 + (gt & 63));
+        GD_STAMP(8);      // per-bead loads issued
     } else {
         for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
     }
-    GD_STAMP(11);     // descriptor + DMA issue
-    // tiled path: the thread's record (written by the build in balanced thread order) names its bead's slot
-    const size_t gt = rbase + blk * GD_BLOCK + tid;
-    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 mo = make_uint2(0u, 0u);
-    if (TILED) { rec = p.rec_x0[gt]; mo = p.rec_mo[gt]; }
-    const unsigned slot = TILED ? (__float_as_uint(rec.w) == 0xffffu ? p.N : blk * GD_BLOCK + __float_as_uint(rec.w)) : blk * GD_BLOCK + tid;
-    const bool valid = slot < p.N;
-    const size_t g = rbase + slot;
-    const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
-    const size_t gl = TILED ? gt : g;        // lists, adjacency chunks: thread order on the tiled path
-    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(gl >> 6) * NCL * 64 + (gl & 63);
-    const uint4 *__restrict__ adj = (const uint4 *)p.badj + (size_t)(gl >> 6) * NCB * 64 + (gl & 63);
+    // generic path: one thread per slot, every independent per-bead load issued up front
+    unsigned slot = blk * GD_BLOCK + tid;
+    bool valid = slot < p.N;
+    size_t g = rbase + slot;
+    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)((TILED ? gt : g) >> 6) * NCL * 64 + ((TILED ? gt : g) & 63);
+    const uint4 *__restrict__ adj = (const uint4 *)p.badj + (size_t)((TILED ? gt : g) >> 6) * NCB * 64 + ((TILED ? gt : g) & 63);
     float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f), x0 = xi4;
     unsigned meta = 0, oid = 0;
-    uint4 adj0 = make_uint4(0, 0, 0, 0), qa = adj0, qb = adj0;
     float mu = p.mob_uniform;
-    if (valid) {
+    if (!TILED && valid) {
         xi4 = p.pos_in[g];
-        if (TILED) { meta = mo.x; oid = mo.y; x0 = rec; }
-        else {
-            meta = p.meta[g];
-            if (MODE != GD_MODE_ENERGY) oid = p.orig[g];
-            if (MODE == GD_MODE_STEP) x0 = p.xb[g];
-        }
+        meta = p.meta[g];
+        if (MODE != GD_MODE_ENERGY) oid = p.orig[g];
+        if (MODE == GD_MODE_STEP) x0 = p.xb[g];
         if (MODE == GD_MODE_STEP && p.mob_uniform < 0.f) mu = p.mob[g];
         if (p.has_bonds) adj0 = adj[0];
-        // list chunks are read once per step and never reused: non-temporal, so they do not displace the tiles'
-        // halo lines (which neighbouring blocks re-read) from the XCD's L2
-        if (p.pair.enabled) { qa = nt_load(&lst[0]); if (!TILED) qb = lst[64]; }
+        if (p.pair.enabled) { qa = lst[0]; qb = lst[64]; }
     }
-    GD_STAMP(8);      // bead loads, bond table, tile DMA issued
+    if (TILED) { meta = mo.x; oid = mo.y; }
+    // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
+    // and the per-bead loads are in flight (the step index comes from a uniform scalar load).  Tiled path: whether the
+    // thread owns a bead is not known yet (that is in the build-position record); threads without one have bead id 0.
+    float3 z = make_float3(0.f, 0.f, 0.f);
+    if (MODE == GD_MODE_STEP && GD_ABL != 14 && (TILED || valid) && p.kT > 0.f) {
+        if (p.noise_mode == NOISE_PHILOX) {
+            const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
+            z = philox_normal3(p.seed, oid, step_now + 1, r);
+        } else if (p.noise_mode == NOISE_HOST) {
+            const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
+            z = make_float3(h[0], h[1], h[2]);
+        }
+    }
 #if GD_ABL == 30
-    asm volatile("" :: "v"(oid));
-    GD_STAMP(9);      // oid arrived
+    asm volatile("" :: "v"(z.x), "v"(z.y), "v"(z.z));
+    GD_STAMP(10);     // noise
 #endif
-    // wave 0: pending callback + float copy of the context for the block (its loads overlap the bead loads above)
+    // wave 0: pending callback + float copy of the context for the block.  After the noise: its vector loads sit behind the
+    // DMAs in the vmcnt order, so this is where wave 0 waits for its share of the tile
     if (wid == 0) {
         DevCtx c = p.ctx_in[r];
         if (MODE == GD_MODE_STEP) {
@@ -382,25 +407,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             }
         }
     }
-    // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
-    // and the per-bead loads are in flight (the step index comes from a uniform scalar load)
-    float3 z = make_float3(0.f, 0.f, 0.f);
-    if (MODE == GD_MODE_STEP && GD_ABL != 14 && valid && p.kT > 0.f) {
-        if (p.noise_mode == NOISE_PHILOX) {
-            const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
-            z = philox_normal3(p.seed, oid, step_now + 1, r);
-        } else if (p.noise_mode == NOISE_HOST) {
-            const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
-            z = make_float3(h[0], h[1], h[2]);
-        }
-    }
-#if GD_ABL == 30
-    asm volatile("" :: "v"(z.x), "v"(z.y), "v"(z.z));
-    GD_STAMP(10);     // noise
-#endif
     GD_STAMP(0);      // prologue: loads issued, tile DMA issued, noise
     __syncthreads();
     GD_STAMP(1);      // barrier (tile arrival)
+    if (TILED) {
+        const unsigned local = __float_as_uint(rec.w);          // block-local slot of the thread's bead, 0xffff: none
+        valid = local != 0xffffu;
+        slot = valid ? blk * GD_BLOCK + local : p.N;
+        g = rbase + slot;
+        if (valid) {
+            // (a truncated tile holds other beads at these indices: take the bead's position from memory, so that the
+            // rolled-back chunk at least leaves plausible positions to the builds that follow in it)
+            xi4 = tile_ok ? s_tile[own_base + local] : p.pos_in[g];
+            x0 = rec;
+            if (MODE == GD_MODE_STEP && p.mob_uniform < 0.f) mu = p.mob[g];
+        }
+    }
 
     const unsigned mask = (MODE == GD_MODE_STEP) ? 63u : p.term_mask;
 
@@ -1021,6 +1043,9 @@ __global__ void k_tiles(const BuildParams p)
         }
         td.nranges = truncated ? 0u : (unsigned)nm;
         td.total = total;
+        td.own_base = 0;
+        for (int k = 0; k < nm && !truncated; k++)
+            if (first - td.start[k] < td.len[k]) td.own_base = td.base[k] + (first - td.start[k]);
         atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
         p.tiles[t] = td;
         return;
@@ -1059,6 +1084,9 @@ __global__ void k_tiles(const BuildParams p)
     }
     td.nranges = truncated ? 0u : (unsigned)nm;
     td.total = total;
+    td.own_base = 0;
+    for (int k = 0; k < nm && !truncated; k++)
+        if (first - td.start[k] < td.len[k]) td.own_base = td.base[k] + (first - td.start[k]);
 
     atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
     p.tiles[t] = td;
@@ -1079,6 +1107,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 #endif
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
+    __shared__ unsigned s_max[GD_BLOCK / 64];
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1371,13 +1400,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     if (TILED && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, 0u); }
     GD_FSTAMP(5);     // padding, meta
     unsigned long long c64 = min(cnt, p.W);
-    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o, 64);
-    if (lane == 0) s_cnt[wid] = c64;
+    unsigned cmax = cnt;
+    for (int o = 32; o > 0; o >>= 1) { c64 += __shfl_xor(c64, o, 64); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o, 64)); }
+    if (lane == 0) { s_cnt[wid] = c64; s_max[wid] = cmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
-        for (int w = 0; w < GD_BLOCK / 64; w++) t += s_cnt[w];
+        unsigned m = 0;
+        for (int w = 0; w < GD_BLOCK / 64; w++) { t += s_cnt[w]; m = max(m, s_max[w]); }
         if (t) atomicAdd(&p.lcount[r], t);
+        if (m) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
     }
     GD_FSTAMP(6);     // count
 #if GD_ABL == 34

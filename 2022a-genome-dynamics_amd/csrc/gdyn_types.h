@@ -45,6 +45,7 @@ struct TileDesc {   // all fields 32-bit: the kernels read it through a block-un
     // per (dz,dy) row offset k: first slot of cell c0+off_k-1 and its LDS index (0xffffffff: no such row)
     unsigned kstart[GD_TILE_RANGES];
     unsigned kbase[GD_TILE_RANGES];
+    unsigned own_base;                     // LDS index of the block's first own slot (blk * GD_BLOCK): k_step reads its beads from the tile
 };
 
 struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
