@@ -65,7 +65,7 @@ class Context(C.Structure):
     _fields_ = [("step", C.c_int64), ("time", C.c_double), ("bead_scale", C.c_double), ("bond_scale", C.c_double),
                 ("semiaxes", C.c_double * 3), ("axial_reaction", C.c_double * 3),
                 ("list_entries", C.c_uint64), ("rebuilds", C.c_uint64), ("rollbacks", C.c_uint64),
-                ("rebuild_interval", C.c_uint32), ("list_radius", C.c_double)]
+                ("rebuild_interval", C.c_uint32), ("list_radius", C.c_double), ("list_path", C.c_uint32)]
 
 
 class _RunDesc(C.Structure):

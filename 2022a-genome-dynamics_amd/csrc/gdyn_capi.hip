@@ -463,6 +463,7 @@ extern "C" int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     memcpy(o->semiaxes, c.semi, sizeof c.semi); memcpy(o->axial_reaction, c.react, sizeof c.react);
     o->list_entries = s->lcount[r]; o->rebuilds = s->rebuilds; o->rollbacks = s->rollbacks;
     o->rebuild_interval = s->K; o->list_radius = s->rv;
+    o->list_path = !s->list_valid && s->rebuilds == 0 ? 0u : (s->list_tiled ? 2u : 1u);
     return GD_OK;
 }
 

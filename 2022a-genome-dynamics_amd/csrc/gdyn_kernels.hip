@@ -314,6 +314,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         // vector load in flight: placed behind the DMAs, its wait would be a wait for the whole tile.  Its latency
         // overlaps the scalar descriptor loads above.
         asm volatile("" : "+v"(mo.x), "+v"(mo.y));
+        GD_STAMP(9);      // record + descriptor arrived
         if (GD_ABL != 12 && (GD_ABL != 33 || (blk & 3u) == 0)) {
             // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
             // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the

@@ -216,6 +216,7 @@ typedef struct {
     uint64_t rollbacks;      /* verified-skin rollbacks since creation */
     uint32_t rebuild_interval;
     double   list_radius;
+    uint32_t list_path;      /* kernel path of the list in use: 0 none yet, 1 generic (global gather), 2 LDS-tiled */
 } gd_context;
 
 int gd_get_context(gd_system *sys, uint32_t replica, gd_context *out);

@@ -189,5 +189,5 @@ def test_1kb_driver_errors(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-def test_1kb_driver_on_gpu(tmp_path, hip):
-    _check(tmp_path, hip, _make("gd_1kb", ".", "../csrc", "gdyn"), atol=5e-4)
+def test_1kb_driver_on_gpu(tmp_path, hip, oracle):
+    _check(tmp_path, oracle, _make("gd_1kb", ".", "../csrc", "gdyn"), atol=5e-4)

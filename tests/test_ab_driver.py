@@ -160,4 +160,4 @@ def test_ab_driver_errors(tmp_path, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("geo", ["box", "sphere", "shell"])
 def test_ab_driver_on_gpu(tmp_path, hip, oracle, geo):
-    _check(tmp_path, hip, oracle, _make("gd_ab_box" if geo == "box" else "gd_ab_sphere", ".", "../csrc", "gdyn"), geo, atol=2e-4)
+    _check(tmp_path, oracle, oracle, _make("gd_ab_box" if geo == "box" else "gd_ab_sphere", ".", "../csrc", "gdyn"), geo, atol=2e-4)

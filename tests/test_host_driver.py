@@ -245,7 +245,7 @@ def test_missing_config_key_is_an_error(tmp_path, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("droplet", [False, True])
 def test_driver_on_gpu(tmp_path, hip, oracle, droplet):
-    _check_run(tmp_path, hip, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), atol=2e-4, droplet=droplet)
+    _check_run(tmp_path, oracle, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), atol=2e-4, droplet=droplet)
 
 
 # ---------------------------------------------------------------------------------------------- gd_spindle
@@ -357,7 +357,7 @@ def test_spindle_driver_on_oracle(tmp_path, oracle):
 
 @pytest.mark.gpu
 def test_spindle_driver_on_gpu(tmp_path, hip, oracle):
-    _check_spindle(tmp_path, hip, oracle, _make("gd_spindle", ".", "../csrc", "gdyn"), atol=2e-4)
+    _check_spindle(tmp_path, oracle, oracle, _make("gd_spindle", ".", "../csrc", "gdyn"), atol=2e-4)
 
 
 # ---------------------------------------------------------------------------------------- gd_fine_sampling
@@ -437,4 +437,4 @@ def test_fine_sampling_driver_on_oracle(tmp_path, oracle):
 
 @pytest.mark.gpu
 def test_fine_sampling_driver_on_gpu(tmp_path, hip, oracle):
-    _check_fine(tmp_path, hip, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), _make("gd_fine_sampling", ".", "../csrc", "gdyn"), atol=2e-4)
+    _check_fine(tmp_path, oracle, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), _make("gd_fine_sampling", ".", "../csrc", "gdyn"), atol=2e-4)

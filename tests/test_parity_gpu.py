@@ -16,8 +16,14 @@ PATHS = {"generic": 1, "tiled": 2}
 
 
 def _paths(name):
-    # the LDS-tiled path serves open boxes; periodic systems use the global-gather path
-    return ["generic", "tiled"] if name in ("genome", "spindle") else ["generic"]
+    # both kernel paths for every configuration (periodic boxes are tiled by whole rows of cells)
+    return ["generic", "tiled"]
+
+
+def _assert_path(s, path):
+    """The list in use was built for the requested kernel path (a forced tiled path silently falls back to the
+    generic one when a tile does not fit: the test must know which one it exercised)."""
+    assert s.context().list_path == PATHS[path], (s.context().list_path, path)
 
 
 def _cases_paths():
@@ -34,6 +40,7 @@ def test_forces_and_energies_vs_golden(hip, name, path):
         F = s.forces(m)
         assert np.abs(F - GOLD[f"{name}/F_{t}"]).max() <= FORCE_RTOL * scale, t
         assert abs(s.energy(m)[0] - GOLD[f"{name}/E_{t}"][0]) <= ENERGY_RTOL * escale, t
+    _assert_path(s, path)
 
 
 @pytest.mark.parametrize("name,path", _cases_paths())
@@ -46,6 +53,7 @@ def test_trajectories_vs_golden(hip, name, path):
         s.set_tuning(kernel_path=PATHS[path])
         s.begin_phase()
         s.run(steps, dt, temp, seed=SEED, noise=noise, flags=flags)
+        _assert_path(s, path)
         scale = max(1.0, np.abs(GOLD[f"{name}/x0"]).max() / 8)          # fp32 ulp grows with |x| (1 kb box ~ 40 units)
         assert np.abs(s.positions() - GOLD[f"{name}/x_{tag}"]).max() <= tol * scale, tag
         c = s.context()
@@ -195,6 +203,112 @@ def test_short_runs_do_not_inflate_the_rebuild_interval(hip):
     c1 = s.context()
     assert c1.rollbacks == c0.rollbacks, (c0.rollbacks, c1.rollbacks)
     assert c1.rebuild_interval <= int(1.3 * k_verified) + 1, (k_verified, c1.rebuild_interval)
+
+
+def test_device_philox_normals_kat(hip, oracle):
+    """The device's Brownian noise against the oracle's Philox4x32-10 + Box-Muller, variate by variate: free beads on
+    a lattice wider than the cutoff (no force acts), mu = 1, dt = 1, kT = 1/2, so one step moves bead i of replica r
+    by exactly the three normals of counter (i, step, r).  8 steps x 32 replicas x 4096 beads = 1.05 M triples, steps
+    on both sides of 2^32 (the counter's high word).  The tiled kernel is the one under test (the pair term is on)."""
+    import ctypes as C
+    n_side, R = 16, 32
+    N = n_side ** 3
+    grid = (np.arange(n_side) - (n_side - 1) / 2) * 0.4
+    x0 = np.stack(np.meshgrid(grid, grid, grid, indexing="ij"), axis=-1).reshape(N, 3)
+    f = oracle.dll.oracle_philox_normal3
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_uint32, C.POINTER(C.c_double)]
+    s = g.System(hip, N, R)
+    s.set_bead_params(a=np.ones(N), b=np.zeros(N))
+    s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
+    s.set_tuning(kernel_path=2, rebuild_interval=1, adapt_interval=0)
+    worst, zs = 0.0, []
+    buf = (C.c_double * 3)()
+    rng = np.random.default_rng(3)
+    for k, step0 in enumerate([0, 1, 2, 1000, 2 ** 32 - 2, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 12345]):
+        s.set_positions(x0)
+        for r in range(R):
+            s.set_context(r, step0, 1.0, 1.0)
+        s.run(1, 1.0, 0.5, seed=SEED + k, noise=g.NOISE_PHILOX)
+        assert s.context().list_path == 2 and s.context(R - 1).step == step0 + 1
+        z = s.positions() - x0[None]
+        zs.append(z)
+        # every variate of 64 random (replica, bead) pairs + the extreme ones, against the oracle's scalar function
+        idx = [(int(r), int(i)) for r, i in zip(rng.integers(0, R, 64), rng.integers(0, N, 64))]
+        flat = np.abs(z).reshape(R, N, 3).max(axis=2)
+        idx += [tuple(int(v) for v in np.unravel_index(np.argmax(flat), flat.shape)), tuple(int(v) for v in np.unravel_index(np.argmin(flat), flat.shape))]
+        for r, i in idx:
+            f(SEED + k, i, step0 + 1, r, buf)
+            worst = max(worst, float(np.abs(z[r, i] - np.array(buf[:])).max()))
+    # fp32 position arithmetic (ulp(4) = 4.8e-7 at the lattice edge) + the hardware log / sin / cos of the Box-Muller
+    assert worst <= 3e-6, worst
+    z = np.concatenate([v.reshape(-1, 3) for v in zs])
+    assert len(z) >= 1_000_000
+    assert abs(z.mean()) < 3e-3 and abs(z.var() - 1) < 3e-3 and abs(np.mean(z ** 4) - 3) < 0.02
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 3e-3 and abs(np.corrcoef(z[:-1, 2], z[1:, 0])[0, 1]) < 3e-3
+    # the whole array against the oracle's own stepper for one of the steps (all 131 072 triples of that step)
+    so = g.System(oracle, N, R)
+    so.set_positions(x0)
+    for r in range(R):
+        so.set_context(r, 2 ** 32 - 1, 1.0, 1.0)
+    so.run(1, 1.0, 0.5, seed=SEED + 5, noise=g.NOISE_PHILOX)
+    assert np.abs((so.positions() - x0[None]) - zs[5]).max() <= 3e-6
+
+
+@pytest.mark.parametrize("n_beads,n_replicas", [(30000, 2), (62178, 1)])
+def test_full_size_genome_vs_oracle(hip, oracle, n_beads, n_replicas):
+    """The production sizes against the oracle directly (one fp64 force / energy evaluation each, plus a 5-step
+    noisy trajectory at 30 000 beads): S-genome-30k and the 62 178-bead production model, tiled path."""
+    sh, info = wl.genome_interphase(hip, n_beads=n_beads, n_replicas=n_replicas, bead_scale_init=0.8)
+    so, _ = wl.genome_interphase(oracle, n_beads=n_beads, n_replicas=n_replicas, bead_scale_init=0.8)
+    Fo = so.forces()
+    scale = np.abs(Fo).max()
+    for t in ("all", "pair", "bond", "wall"):
+        Fh, Fr = sh.forces(TERMS[t]), (Fo if t == "all" else so.forces(TERMS[t]))
+        assert np.abs(Fh - Fr).max() <= FORCE_RTOL * scale, t
+    assert sh.context().list_path == 2
+    eo = so.energy()
+    assert np.all(np.abs(sh.energy() - eo) <= 3 * ENERGY_RTOL * np.abs(eo))
+    if n_beads == 30000:
+        flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+        for s in (sh, so):
+            s.begin_phase()
+            s.run(5, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+        assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
+        for r in range(n_replicas):
+            assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), rtol=0, atol=1e-8)
+            assert np.allclose(np.array(sh.context(r).axial_reaction), np.array(so.context(r).axial_reaction), rtol=2e-4, atol=1e-2)
+
+
+def test_full_size_1kb_vs_oracle(hip, oracle):
+    """S-1kb-250k (periodic box, repulsion + attraction, springs, bending, loops, glues) against one oracle evaluation."""
+    sh, info = wl.chromatin_1kb(hip, n_beads=250000)
+    so, _ = wl.chromatin_1kb(oracle, n_beads=250000)
+    Fo = so.forces()
+    scale = np.abs(Fo).max()
+    assert np.abs(sh.forces() - Fo).max() <= FORCE_RTOL * scale
+    for t in ("pair", "bond", "bend", "dynamic"):
+        assert np.abs(sh.forces(TERMS[t]) - so.forces(TERMS[t])).max() <= FORCE_RTOL * scale, t
+    eo = so.energy()
+    assert abs(sh.energy()[0] - eo[0]) <= 3 * ENERGY_RTOL * sum(abs(so.energy(TERMS[t])[0]) for t in ("pair", "bond", "bend", "dynamic"))
+
+
+def test_wall_context_on_a_grid_larger_than_the_chip(hip, oracle):
+    """30 000 beads x 16 replicas = 944 blocks, more than are resident at once (256 CUs x 3): the per-step callback
+    state (semiaxes, axial reaction: reduced from per-block partials by every block's prologue) must not depend on
+    which blocks of the previous step have already been replaced -- the partials are double-buffered."""
+    R = 16
+    sh, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R, bead_scale_init=0.9)
+    so, _ = wl.genome_interphase(oracle, n_beads=30000, n_replicas=R, bead_scale_init=0.9)
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    for s in (sh, so):
+        s.begin_phase()
+        s.run(12, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+    for r in range(R):
+        ch, co = sh.context(r), so.context(r)
+        assert ch.step == co.step == 12
+        assert np.allclose(np.array(ch.semiaxes), np.array(co.semiaxes), rtol=0, atol=2e-9), r
+        assert np.allclose(np.array(ch.axial_reaction), np.array(co.axial_reaction), rtol=3e-4, atol=2e-2), r
+    assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
 
 
 # ---------------------------------------------------------------- BASELINE sizes

@@ -15,11 +15,12 @@ if os.path.exists(snap):
 else:
     s.begin_phase(); s.run(EQ, 1e-5, 1.0, seed=99, flags=0); np.save(snap, s.positions())
 s.begin_phase()
-s.run(8, 1e-5, 1.0, seed=3, flags=3)
+if not os.environ.get("GDYN_NO_RUN"):      # ablation builds: no stepping with the ablated kernels, time them on the relaxed snapshot
+    s.run(8, 1e-5, 1.0, seed=3, flags=3)
 c = s.context()
 print(f"lib {os.environ.get('GDYN_LIB','libgdyn.so')}: build {s.debug_bench(0, 20)*1e3:.1f} us  step {s.debug_bench(1, 40)*1e3:.1f} us   L/bead {c.list_entries/30000:.1f} K {c.rebuild_interval}")
 if os.environ.get("GDYN_STAMPS"):
-    names = ["ctx/tail-of-prologue", "barrier", "pairs", "bonds", "bend+ps", "wall", "integrate", "perm", "dma-issue", "oid", "noise", "bead-loads-issue"]
+    names = ["ctx/tail-of-prologue", "barrier", "pairs", "bonds", "bend+ps", "wall", "integrate", "perm", "loads-issue", "rec+desc", "noise", "dma-issue"]
     vals = [s.debug_bench(10 + k, 20) for k in range(12)]
     print("   cycles/wave: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
 if os.environ.get("GDYN_FSTAMPS"):
