@@ -825,7 +825,10 @@ static float list_radius(gd_system *s, const gd_run_desc *run, uint32_t ahead)
     const float cut = pair_cutoff(s);
     if (!(cut > 0)) return 1.0f;
     const double sc = s->pair.scale_by_bead_scale ? bead_scale_bound(s, run, ahead) : 1.0;
-    return (float)(cut * sc * (1.0 + s->skin));
+    // the skin is an absolute width, `skin` x the NOMINAL cutoff: with a scaled-down cutoff (bead_scale < 1 early in the
+    // interphase run, simulation_driver_forcefield.cc:47-49) the displacement budget (rv - cutoff) / 2, and with it the
+    // rebuild interval, stays what it is at full scale
+    return (float)(cut * (sc + s->skin));
 }
 
 static int ensure_fresh_list(gd_system *s)

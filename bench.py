@@ -71,7 +71,7 @@ def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
     farm = None
     fast = os.path.join(ROOT, "oracle", "liboracle_fast.so")
     try:
-        cores = min(len(os.sched_getaffinity(0)), 16)
+        cores = min(len(os.sched_getaffinity(0)), 64)      # the GPU box grants 16 per GPU; stated in the result
         if os.path.exists(fast) and cores > 1:
             fsteps, fel = _oracle_rate(g, wl, fast, x0, n_beads, 2.0)
             fsteps = int(max(10, budget_s * 0.6 * fsteps / fel))      # the loaded machine runs slower than the 1-core probe
@@ -98,6 +98,46 @@ def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
     return base, farm
 
 
+def other_workloads(g, wl, hip, dev_index, budget_steps=600):
+    """The measurements BASELINE.md / SURVEY 8d list beside the headline, each after its own (short) relaxation, same
+    clock as the headline (wall time of gd_run): ms per step, bead-steps/s, rollbacks.  Reported under config.other_workloads."""
+    out = []
+
+    def run_one(tag, make, flags, relax, steps):
+        s, info = make()
+        dt, kT = info["timestep"], info["temperature"]
+        N, R = info["n_beads"], s.R
+        s.begin_phase()
+        if relax:
+            s.run(relax, dt, kT, seed=5, flags=0)
+            s.begin_phase()
+        s.run(max(steps // 4, 40), dt, kT, seed=6, flags=flags)
+        rb0 = s.context().rollbacks
+        t0 = time.perf_counter()
+        tm = s.run(steps, dt, kT, seed=7, flags=flags)
+        el = time.perf_counter() - t0
+        c = s.context()
+        out.append({"workload": tag, "n_beads": N, "replicas": R, "steps": steps, "relax_steps": relax,
+                    "bead_steps_per_s": N * R * steps / el, "ms_per_step": el / steps * 1e3,
+                    "k_step_ms": tm.step_kernel_ms / max(tm.step_launches, 1), "rebuild_ms_per_step": tm.rebuild_ms / max(tm.step_launches, 1),
+                    "list_entries_per_bead": c.list_entries / N, "rebuild_interval": int(c.rebuild_interval),
+                    "rollbacks_in_timed_steps": int(c.rollbacks - rb0), "kernel_path": {0: "none", 1: "generic", 2: "tiled"}[c.list_path]})
+        s.close()
+
+    f3 = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    run_one("S-genome-30k x 1 replica (what one reference-shaped driver process runs)",
+            lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=1, device=dev_index), f3, 4000, 2 * budget_steps)
+    run_one("S-genome-62k x 32 replicas (production bead count)",
+            lambda: wl.genome_interphase(hip, n_beads=62178, n_replicas=32, device=dev_index), f3, 4000, budget_steps)
+    run_one("S-genome-30k x 128, bead_scale_init 0.5 (time-varying cutoff, simulation_driver_forcefield.cc:47-49)",
+            lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, bead_scale_init=0.5, device=dev_index), f3, 4000, budget_steps)
+    run_one("S-genome-30k x 128, 2nd-bond spring 0 (variant of SURVEY 8d)",
+            lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, second_bond_spring=0.0, device=dev_index), f3, 4000, budget_steps)
+    run_one("S-1kb-250k x 4 replicas (periodic, loops + glues static)",
+            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=4, device=dev_index), 0, 300, budget_steps // 2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +148,7 @@ def main():
     ap.add_argument("--equil", type=int, default=20000,
                     help="untimed relaxation steps before warmup (SURVEY 8d cfg3: 20 000 from the random-walk start)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other workloads of the measurement row (config.other_workloads)")
     ap.add_argument("--save-state", default="", help="write the relaxed positions (after --equil) to this .npy and exit")
     ap.add_argument("--load-state", default="", help="start from relaxed positions saved by --save-state (no relaxation "
                     "launches: used for the committed rocprof summaries, so that kernel averages cover the timed state only)")
@@ -166,11 +207,13 @@ def main():
     if a.warmup > 0:
         sys_.run(a.warmup, dt, kT, seed=seed, flags=flags)
 
+    rb0 = sys_.context(0).rollbacks
     farm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     tm = sys_.run(a.steps, dt, kT, seed=seed, flags=flags)      # synchronous: returns after the stream drained
     torch.cuda.synchronize(); farm.barrier()
     el = farm.max_over_ranks(time.perf_counter() - t0, device=tdev)
+    rollbacks_timed = sys_.context(0).rollbacks - rb0
 
     # second figure: the same stepping with the reference's observation cadence -- mean energy every
     # interphase_logging_interval = 100 steps, a quantised snapshot every interphase_sampling_interval = 1000 steps
@@ -196,18 +239,27 @@ def main():
     gathered = farm.gather_stats([e_mean, ctx.semiaxes[0], float(ctx.rebuild_interval), float(ctx.rollbacks)], device=tdev)
 
     if rank == 0:
-        traffic = None      # HBM bytes per k_step launch from the committed PMC passes, if they are for this workload
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj["workload"] == {"n_beads": N, "replicas_per_gpu": R}:
-                traffic = tj["k_step"]["corrected_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes per k_step launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this very
+        # workload, profiles/README.md); a cached profile value, not a measurement of this run: counters cannot be read
+        # from inside the process
+        traffic, traffic_src = None, None
+        for name in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if tj["workload"] == {"n_beads": N, "replicas_per_gpu": R}:
+                    traffic, traffic_src = tj["k_step"]["corrected_bytes_per_launch"], "profiles/" + name
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         launches = max(int(tm.step_launches), 1)
         L_launch = tm.list_entries_visited / launches                 # directed entries, all replicas
-        bytes_launch = 44.0 * N * R + 28.0 * L_launch                 # 44 N + 28 L per replica-step
-        kms = tm.step_kernel_ms / launches
-        achieved = bytes_launch / (kms * 1e-3) / 1e9
+        kms = tm.step_kernel_ms / launches                            # HIP events on the handle's stream around the step launches
+        # SURVEY 8d's per-unit figure: 204 B per bead-step (44 N + 28 L at the reference list L = 5.7 N) -- a list-length-
+        # independent price: the bytes a gather-from-HBM design with a 1.2 x cutoff list would move.  The tiled kernel
+        # reads neighbours from LDS and keeps a longer list (2 B per entry), so its own traffic is the PMC figure.
+        alg_bytes = 204.0 * N * R
+        alg_gbs = alg_bytes / (kms * 1e-3) / 1e9
+        meas_gbs = traffic / (kms * 1e-3) / 1e9 if traffic else None
         out = {
             "metric": "bead-steps/sec on 100kb whole-genome model, 1 GPU and 8-GPU replica farm",
             "value": N * R * world * a.steps / el, "unit": "bead-steps/s",
@@ -217,14 +269,18 @@ def main():
                        "n_beads": N, "replicas_per_gpu": R, "global_replicas": R * world, "parallelism": f"replica-farm x{world}",
                        "timestep": dt, "temperature": kT, "list_entries_per_bead": L_launch / (N * R),
                        "rebuild_interval": int(ctx.rebuild_interval), "list_radius": ctx.list_radius,
-                       "rollbacks": int(ctx.rollbacks), "equil_steps": a.equil,
+                       "rollbacks": int(ctx.rollbacks), "rollbacks_in_timed_steps": int(rollbacks_timed), "equil_steps": a.equil,
                        "bead_steps_per_s_with_reference_cadence_rank0": obs_rate,
                        "mean_energy_per_bead": [float(v[0]) for v in gathered], "wall_semiaxis": [float(v[1]) for v in gathered]},
-            "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kms,
-                         # the list length is a tuning choice (skin); the same rate priced at SURVEY 8d's reference
-                         # list (L = 5.7 N, 204 B per bead-step) over the WHOLE step (rebuilds included):
+            # frac = measured HBM bytes of the dominant kernel / its launch time / 8 TB/s (<= 1 by construction); the
+            # algorithmic figure at SURVEY's list-independent price is the second key
+            "roofline": {"bound": "hbm", "kernel": "k_step", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "achieved": meas_gbs if meas_gbs is not None else alg_gbs,
+                         "frac": (meas_gbs if meas_gbs is not None else alg_gbs) / HBM_PEAK_GBS,
+                         "frac_kind": "pmc_traffic_over_live_kernel_time" if meas_gbs is not None else "survey_204B_per_bead_step_over_live_kernel_time",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch_at_survey_list": alg_bytes, "algorithmic_frac_at_survey_list": alg_gbs / HBM_PEAK_GBS,
+                         "avg_launch_ms": kms,
                          "whole_step_frac_at_survey_list": 204.0 * N * R * a.steps / el / 1e9 / HBM_PEAK_GBS,
                          "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},
         }
@@ -232,7 +288,10 @@ def main():
             out["cpu_baseline"], farm_cpu = cpu_baseline(g, wl, sys_.positions()[0], N)
             out["config"]["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
             if farm_cpu is not None:
-                out["config"]["cpu_farm_all_host_threads"] = farm_cpu
+                out["config"]["cpu_farm_one_replica_per_core"] = farm_cpu      # `cores` = the cores this process may run on (affinity)
+        if not a.no_extra and world == 1:
+            sys_.close()
+            out["config"]["other_workloads"] = other_workloads(g, wl, hip, dev_index)
         print(json.dumps(out), flush=True)
     sys_.close()
     if world > 1:
