@@ -141,6 +141,8 @@ struct gd_system {
     float mob_uniform = -1.f;
     DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part[2]; DevBuf<double> epart;   // react_part ping-pongs with ctx
     DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
+    DevBuf<CtxF> ctxf;             // float context of the coming step (k_ctx -> k_step_p)
+    unsigned n_cu = 256;           // compute units of the device: grid of the persistent step kernel
     int ocur = 0;   // which orig[] buffer is current
     std::vector<hipEvent_t> events;
     ~gd_system()
@@ -192,12 +194,13 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
-         s->lcount_d.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
+         s->lcount_d.resize(s->R) == hipSuccess && s->ctxf.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess;
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
     gd_launch_identity(s->orig[0].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     if (hipStreamSynchronize(s->stream) != hipSuccess) { delete s; return fail(GD_EHIP, "gd_create: identity kernel failed"); }
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && v > 0) s->n_cu = (unsigned)v; }
     *out = s;
     return GD_OK;
 }
@@ -499,7 +502,7 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
     s->adapt = t->adapt_interval;
     if (t->list_width > 0 && t->list_width != s->W) { (void)s->nbr.resize(0); s->W = t->list_width; }
-    if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0, 1 or 2");
+    if (t->kernel_path > 3) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..3");
     s->kernel_path = t->kernel_path; s->tiled_ok = true; s->tiled_off = 0;
     s->list_valid = false;
     return GD_OK;
@@ -638,7 +641,7 @@ static void fill_common(gd_system *s, StepParams &p)
     p.cpb = s->cpb; p.tile_cap = s->list_tiled ? s->list_tile_cap : s->tile_cap;   // as at the build of the list in use
     p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
     p.meta = s->meta.p; p.rec_x0 = s->rec_x0.p; p.rec_mo = s->rec_mo.p; p.W = s->list_W; p.badj = s->badj.p; p.chain = s->chain.p;
-    p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.flags = s->flags.p;
+    p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.ctxf = s->ctxf.p; p.flags = s->flags.p;
     // wall-reaction partials ping-pong with the context: a launch reads the previous step's partials while its blocks
     // write this step's (one buffer would let late blocks read a mix of two steps)
     p.react_in = s->react_part[s->ccur].p; p.react_out = s->react_part[s->ccur ^ 1].p;
@@ -679,7 +682,7 @@ static void fill_common(gd_system *s, StepParams &p)
 // Enqueue one list build (counting sort into slot order + ELL fill) with radius rv.
 static bool want_tiled(const gd_system *s)
 {
-    return s->kernel_path != 1 && s->tiled_ok && s->packed_ab;      // open and periodic boxes alike
+    return s->kernel_path != 1 && s->tiled_ok && s->packed_ab && s->W <= GD_TILED_MAX_W;      // open and periodic boxes alike
 }
 
 static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tiled = true)
@@ -735,7 +738,7 @@ static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (siz
 static unsigned pick_tile_cap(unsigned need)
 {
     // LDS is granted in 1280-byte granules (measured with 1184 B of static LDS: 3264 entries fit 3 blocks, 3318 do not; 720 B now)
-    static std::vector<unsigned> caps = {3312u, 5072u, 8192u};
+    static std::vector<unsigned> caps = {3312u, 4080u, 5072u, 8192u};      // (4080: the largest tile of the persistent step kernel, byte-offset entries)
     static bool init = false;
     if (!init) {      // experiment hook: GDYN_TILE_CAPS=a,b,c
         if (const char *e = dev_env("GDYN_TILE_CAPS")) { caps.clear(); for (const char *q = e; *q;) { caps.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
@@ -910,7 +913,11 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 // evaluation of a COMPLETE interval only (a chunk that ends mid-interval records nothing and adapts nothing)
                 p.record_disp = (s->steps_since_build + (uint32_t)q + 1u == s->K);
                 full_interval |= p.record_disp != 0;
-                gd_launch_step(p, GD_MODE_STEP, s->stream);
+                if (s->kernel_path == 3 && gd_step_p_eligible(p)) {
+                    // (opt-in) persistent, software-pipelined step kernel: the callback state of the step is advanced by k_ctx first
+                    gd_launch_finalize(p, 2, s->stream);
+                    gd_launch_step_p(p, s->n_cu, s->stream);
+                } else gd_launch_step(p, GD_MODE_STEP, s->stream);
                 if (s->sw_n) launch_softwell(s, p, 0);
                 s->pcur ^= 1; s->ccur ^= 1;
             }
@@ -1090,6 +1097,7 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
     HIPCHK(hipEventRecord(e0, s->stream));
     for (int i = 0; i < n; i++) {
         if (what == 0 || what >= 30) { GDCHK(enqueue_build(s, rv, pair_cutoff(s) > 0)); }
+        else if (s->kernel_path == 3 && gd_step_p_eligible(p)) { gd_launch_finalize(p, 2, s->stream); gd_launch_step_p(p, s->n_cu, s->stream); }
         else gd_launch_step(p, GD_MODE_STEP, s->stream);
     }
     HIPCHK(hipEventRecord(e1, s->stream));

@@ -25,6 +25,8 @@
 #define GD_CHAIN_LOCAL 0x40000000          // same for chain (bending) partners
 #define GD_TILE_RANGES 9                   // (dz,dy) rows of the 27-cell neighbourhood
 #define GD_XCDS 8
+#define GD_REC_NONE 0x3ffu                 // tiled per-thread record: block-local slot field of a thread without a bead
+#define GD_TILED_MAX_W 1016u                // list length field of the tiled record: 10 bits
 #define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 
 enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
@@ -41,12 +43,16 @@ struct TileDesc {   // all fields 32-bit: the kernels read it through a block-un
     unsigned len[GD_TILE_RANGES];          // slots in the range
     unsigned base[GD_TILE_RANGES];         // LDS index of the range's first slot
     unsigned total;                        // beads staged
-    unsigned nranges;                      // merged ranges in use
+    unsigned nranges;                      // merged ranges in use (0: the tile did not fit)
+    unsigned own_base;                     // LDS index of the block's first own slot (blk * GD_BLOCK): k_step reads its beads from the tile
+    unsigned pad_[2];                      // (the first 32 dwords are what k_step_p stages per tile)
     // per (dz,dy) row offset k: first slot of cell c0+off_k-1 and its LDS index (0xffffffff: no such row)
     unsigned kstart[GD_TILE_RANGES];
     unsigned kbase[GD_TILE_RANGES];
-    unsigned own_base;                     // LDS index of the block's first own slot (blk * GD_BLOCK): k_step reads its beads from the tile
 };
+#define GD_TD_TOTAL 27
+#define GD_TD_NRANGES 28
+#define GD_TD_OWN 29
 
 struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
     long long step;
@@ -56,6 +62,16 @@ struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
     double semi[3];
     double react[3];            // axial_reaction of the last force evaluation
 };
+
+struct CtxF {                   // float copy of DevCtx + block-uniform wall constants; 80 bytes = 20 dwords (k_step_p stages it lane by lane)
+    long long step;
+    float bead_scale, bond_scale, semi[3];
+    float inv_semi[3], inv_semi2[3];
+    float inv_bond_scale2;
+    float near2;                // a bead can touch the wall only if C + 1 >= near2 (see the wall section); <= 0: always
+    float w_inv_sa2, w_inv_sb2, w_ca, w_cb;     // soft wall (half diameters, bead scale): 1/s^2, 6 eps_a / sa^2, 24 eps_b / sb^2
+};
+static_assert(sizeof(CtxF) == 80, "CtxF is staged as 20 dwords");
 
 struct GridP {                  // per replica cell grid of the last list build
     float org[3];
@@ -140,6 +156,7 @@ struct StepParams {
     // context
     const DevCtx *ctx_in;
     DevCtx *ctx_out;
+    CtxF *ctxf;                         // [R] float context of the coming step (k_ctx mode 2 -> k_step_p)
     const float4 *react_in;             // [R][nblk] wall-reaction partials of the previous step (read by the callback)
     float4 *react_out;                  // [R][nblk] this step's partials (double-buffered with the context)
     unsigned *flags;
@@ -215,7 +232,9 @@ struct BuildParams {
 
 // launchers (gdyn_kernels.hip)
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
-void gd_launch_finalize(const StepParams &p, int reduce_only, hipStream_t st);
+void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st);     // k_ctx: 0 final callback, 1 fold reaction partials, 2 per-step (k_step_p)
+bool gd_step_p_eligible(const StepParams &p);
+void gd_launch_step_p(const StepParams &p, unsigned n_cu, hipStream_t st);
 void gd_launch_build(const BuildParams &p, hipStream_t st);
 // Droplet attraction among a small set of target beads (gd_set_pair_softwell): all pairs, one thread per target.
 struct SoftwellP {

@@ -28,3 +28,7 @@ if os.environ.get("GDYN_FSTAMPS"):
     vals = [s.debug_bench(30 + k, 10) for k in range(7)]
     print("   lane-0 test groups per wave %.1f, append iterations %.1f" % (s.debug_bench(38, 10) / 10, s.debug_bench(39, 10) / 10))
     print("   k_fill cycles/wave: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
+if os.environ.get("GDYN_PSTAMPS"):
+    names = ["tail", "vmcnt-wait", "barrier", "epilogue", "prefetch-issue", "own+noise", "pairs", "bonds+wall"]
+    vals = [s.debug_bench(10 + k, 20) for k in range(8)]
+    print("   k_step_p cycles/wave (all tiles): " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
