@@ -142,6 +142,10 @@ struct gd_system {
     DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part[2]; DevBuf<double> epart;   // react_part ping-pongs with ctx
     DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
     DevBuf<CtxF> ctxf;             // float context of the coming step (k_ctx -> k_step_p)
+    // gd_search_pairs: device output, counters, and the cached result of the last call
+    DevBuf<uint2> sp_out; DevBuf<unsigned long long> sp_count; std::vector<uint2> sp_host;
+    bool sp_valid = false; uint32_t sp_r = 0; double sp_dcut = 0; uint64_t sp_serial = 0;
+    uint64_t state_serial = 1;     // bumped by everything that changes positions or the model (invalidates the cache)
     unsigned n_cu = 256;           // compute units of the device: grid of the persistent step kernel
     int ocur = 0;   // which orig[] buffer is current
     std::vector<hipEvent_t> events;
@@ -249,7 +253,7 @@ extern "C" int gd_set_positions(gd_system *s, const double *xyz)
                             (size_t)s->N * sizeof(float4), s->R, hipMemcpyHostToDevice, s->stream));
     gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->list_valid = false;
+    s->list_valid = false; s->state_serial++;
     return GD_OK;
 }
 
@@ -861,6 +865,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     if ((run->flags & GD_RUN_WALL_DYNAMICS) && !s->has_wall) return fail(GD_ESTATE, "gd_run: wall dynamics requested without a wall");
     if ((run->flags & GD_RUN_UPDATE_SCALES) && !s->has_scaling) return fail(GD_ESTATE, "gd_run: scale updates requested without gd_set_scaling");
     GDCHK(prepare(s));
+    s->state_serial++;
     const bool with_list = pair_cutoff(s) > 0;
     const size_t RN = (size_t)s->R * s->N;
     memset(&s->timing, 0, sizeof s->timing);
@@ -1051,30 +1056,54 @@ extern "C" int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
     return GD_OK;
 }
 
+// md::neighbor_searcher{box, dcut}.search(): served on the device from the resident Verlet list when that list is
+// complete for dcut (dcut + 2 x largest displacement since the build <= list radius), after ONE list build otherwise -- a
+// build at radius max(force-list radius, dcut), so the force list stays valid either way and the next gd_run does not rebuild.
+// The result is cached for the repeated call of the count-then-fetch idiom.
 extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *pairs, uint64_t cap, uint64_t *n_pairs)
 {
     if (!s || !n_pairs || (cap && !pairs)) return fail(GD_EINVAL, "gd_search_pairs: NULL argument");
     if (r >= s->R || !(dcut > 0)) return fail(GD_EINVAL, "gd_search_pairs: bad replica or cutoff");
     GDCHK(prepare(s));
-    GDCHK(build_now(s, (float)dcut, true, false));   // generic (global-slot) list
-    s->list_valid = false;   // the force list was overwritten with the search radius
-    const uint32_t N = s->N, W = s->list_W, NC = W / 4;
-    std::vector<unsigned> cnt(N), org(N);
-    HIPCHK(hipMemcpy(cnt.data(), s->meta.p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
-    for (auto &c : cnt) c >>= 16;
-    HIPCHK(hipMemcpy(org.data(), s->orig[s->ocur].p + (size_t)r * s->Np, N * sizeof(unsigned), hipMemcpyDeviceToHost));
-    // generic list layout: chunk c (4 slots) of bead g is uint4 #((g/64)*NC + c)*64 + g%64
-    const size_t wave0 = ((size_t)r * s->Np) / 64, nwaves = s->Np / 64;
-    std::vector<uint4> lst((size_t)nwaves * NC * 64);
-    HIPCHK(hipMemcpy(lst.data(), (const uint4 *)s->nbr.p + wave0 * NC * 64, lst.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-    uint64_t n = 0;
-    for (uint32_t sl = 0; sl < N; sl++)
-        for (uint32_t k = 0; k < cnt[sl]; k++) {
-            const uint4 q = lst[((size_t)(sl / 64) * NC + k / 4) * 64 + sl % 64];
-            const unsigned js = (k % 4 == 0) ? q.x : (k % 4 == 1) ? q.y : (k % 4 == 2) ? q.z : q.w;
-            const uint32_t i = org[sl], j = org[js];
-            if (i < j) { if (n < cap) { pairs[2 * n] = i; pairs[2 * n + 1] = j; } n++; }
+    if (!(s->sp_valid && s->sp_r == r && s->sp_dcut == dcut && s->sp_serial == s->state_serial)) {
+        const bool with_list = pair_cutoff(s) > 0;
+        if (!s->sp_out.p) HIPCHK(s->sp_out.resize(std::max<size_t>((size_t)s->N * 8, 4096), false));
+        HIPCHK(s->sp_count.resize(2));
+        bool done = false;
+        for (int attempt = 0; attempt < 6 && !done; attempt++) {
+            if (!s->list_valid || !((float)dcut <= s->rv) || s->list_W == 0) {
+                const float rv_force = with_list ? list_radius(s, nullptr, 0) : 0.f;
+                GDCHK(build_now(s, std::max(rv_force, (float)(dcut * (1.0 + 1e-6))), true));
+                s->list_valid = true;
+            }
+            const double lim = 0.5 * ((double)s->rv - dcut);
+            PairsP q;
+            memset(&q, 0, sizeof q);
+            q.pos = s->pos[s->pcur].p; q.x0 = s->list_tiled ? s->rec_x0.p : s->xb.p; q.rec_mo = s->rec_mo.p; q.meta = s->meta.p;
+            q.orig = s->orig[s->ocur].p; q.nbr = s->nbr.p; q.nbr16 = s->nbr16.p; q.tiles = s->tiles.p;
+            q.N = s->N; q.Np = s->Np; q.nblk = s->nblk; q.r = r; q.W = s->list_W;
+            q.tiled = s->list_tiled ? 1 : 0; q.s16 = (s->list_tiled && s->list_tile_cap < 4096u) ? 1 : 0;
+            q.periodic = s->box_kind == GD_BOX_PERIODIC;
+            for (int k = 0; k < 3; k++) { q.box[k] = (float)s->box[k]; q.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
+            q.dcut2 = (float)(dcut * dcut); q.lim2 = (float)(lim * lim);
+            q.out = s->sp_out.p; q.cap = s->sp_out.n; q.count = s->sp_count.p;
+            HIPCHK(hipMemsetAsync(s->sp_count.p, 0, 2 * sizeof(unsigned long long), s->stream));
+            gd_launch_pairs(q, s->stream);
+            unsigned long long cnt[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(cnt, s->sp_count.p, sizeof cnt, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipGetLastError());
+            if (cnt[1]) { s->list_valid = false; continue; }                 // a bead moved beyond the margin: fresh list
+            if (cnt[0] > s->sp_out.n) { HIPCHK(s->sp_out.resize((size_t)(cnt[0] + cnt[0] / 8 + 64), false)); continue; }
+            s->sp_host.resize((size_t)cnt[0]);
+            if (cnt[0]) HIPCHK(hipMemcpy(s->sp_host.data(), s->sp_out.p, (size_t)cnt[0] * sizeof(uint2), hipMemcpyDeviceToHost));
+            done = true;
         }
+        if (!done) return fail(GD_ESTATE, "gd_search_pairs: did not converge");
+        s->sp_valid = true; s->sp_r = r; s->sp_dcut = dcut; s->sp_serial = s->state_serial;
+    }
+    const uint64_t n = s->sp_host.size();
+    for (uint64_t k = 0; k < n && k < cap; k++) { pairs[2 * k] = s->sp_host[k].x; pairs[2 * k + 1] = s->sp_host[k].y; }
     *n_pairs = n;
     return GD_OK;
 }

@@ -2005,6 +2005,81 @@ void gd_launch_softwell(const SoftwellP &p, int mode, hipStream_t st)
     else hipLaunchKernelGGL(k_softwell<2>, grid, block, lds, st, p);
 }
 
+// ------------------------------------------------------------- pair search
+// md::neighbor_searcher<Box>{box, dcut}.search(out) (simulation_interphase/contact_map.cc:64-66, glues/glue_simulator.cpp:41,67-77)
+// served from the RESIDENT Verlet list: every pair closer than dcut now was closer than dcut + 2 D at the build (D = largest
+// displacement since), so for dcut + 2 D <= list radius the list holds them all -- no rebuild, no list download.  One thread per
+// list owner: entries within dcut whose partner has the larger bead id are appended to the output (wave-aggregated atomic).
+template <bool TILED>
+__global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
+{
+    __shared__ TileDesc s_td;
+    const unsigned blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const size_t rbase = (size_t)p.r * p.Np, gt = rbase + blk * GD_BLOCK + tid;
+    if (TILED) {
+        const unsigned *src = (const unsigned *)(p.tiles + (size_t)p.r * p.nblk + blk);
+        if (tid < sizeof(TileDesc) / 4) ((unsigned *)&s_td)[tid] = src[tid];
+        __syncthreads();
+    }
+    unsigned slot = blk * GD_BLOCK + tid, cnt = 0;
+    bool valid = slot < p.N;
+    if (TILED) {
+        const uint2 mo = p.rec_mo[gt];
+        const unsigned local = (mo.x >> 12) & 0x3ffu;
+        valid = local != GD_REC_NONE; slot = blk * GD_BLOCK + (valid ? local : 0u); cnt = mo.x >> 22;
+    } else if (valid) cnt = p.meta[rbase + slot] >> 16;
+    const float4 *__restrict__ rpos = p.pos + rbase;
+    float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned oi = 0;
+    if (valid) {
+        xi = rpos[slot]; oi = p.orig[rbase + slot];
+        const float4 x0 = TILED ? p.x0[gt] : p.x0[rbase + slot];
+        const float dx = xi.x - x0.x, dy = xi.y - x0.y, dz = xi.z - x0.z;
+        if (dx * dx + dy * dy + dz * dz > p.lim2) p.count[1] = 1ull;
+    } else cnt = 0;
+    const size_t gl = TILED ? gt : rbase + slot;
+    const unsigned PER = TILED ? 8u : 4u, NC = p.W / PER;
+    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(gl >> 6) * NC * 64 + (gl & 63);
+    auto partner = [&](unsigned k) -> unsigned {       // slot of list entry k
+        const uint4 q = lst[(size_t)(k / PER) * 64];
+        const unsigned w = k % PER;
+        if (!TILED) return w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
+        const unsigned word = (w >> 1) == 0 ? q.x : (w >> 1) == 1 ? q.y : (w >> 1) == 2 ? q.z : q.w;
+        unsigned idx = (w & 1u) ? word >> 16 : word & 0xffffu;
+        if (p.s16) idx >>= 4;
+        for (int k2 = 0; k2 < GD_TILE_RANGES; k2++) { const unsigned d = idx - s_td.base[k2]; if (d < s_td.len[k2]) return s_td.start[k2] + d; }
+        return slot;      // (cannot happen for a complete tile; the bead itself is no pair)
+    };
+    auto close_pair = [&](unsigned js, unsigned &oj) -> bool {
+        if (js == slot) return false;
+        const float4 xj = rpos[js];
+        float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+        if (p.periodic) d = min_image(d, p.box, p.inv_box);
+        if (!(d.x * d.x + d.y * d.y + d.z * d.z < p.dcut2)) return false;
+        oj = p.orig[rbase + js];
+        return oi < oj;
+    };
+    unsigned n = 0, oj;
+    for (unsigned k = 0; k < cnt; k++) n += close_pair(partner(k), oj) ? 1u : 0u;
+    // wave-aggregated append: exclusive scan of the lane counts, one atomic per wave
+    unsigned incl = n;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+    const unsigned total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 63 && total) base = atomicAdd(p.count, (unsigned long long)total);
+    base = __shfl(base, 63, 64);
+    unsigned long long at = base + (incl - n);
+    if (n && at + n <= p.cap)
+        for (unsigned k = 0; k < cnt; k++)
+            if (close_pair(partner(k), oj)) p.out[at++] = make_uint2(oi, oj);
+}
+
+void gd_launch_pairs(const PairsP &p, hipStream_t st)
+{
+    if (p.tiled) hipLaunchKernelGGL(k_pairs<true>, dim3(p.nblk), dim3(GD_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL(k_pairs<false>, dim3(p.nblk), dim3(GD_BLOCK), 0, st, p);
+}
+
 // ------------------------------------------------------------------- misc
 
 __global__ void k_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np, int quantize)

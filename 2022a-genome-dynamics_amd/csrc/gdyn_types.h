@@ -250,6 +250,19 @@ struct SoftwellP {
     float box[3], inv_box[3];
 };
 void gd_launch_softwell(const SoftwellP &p, int mode, hipStream_t st);
+// Unique pairs (bead ids i < j) of one replica closer than dcut, filtered from the RESIDENT Verlet list (k_pairs)
+struct PairsP {
+    const float4 *pos, *x0;             // current positions (slot order); build positions: rec_x0 (tiled, thread order) or xb (slot order)
+    const uint2 *rec_mo; const unsigned *meta, *orig;
+    const unsigned *nbr; const unsigned short *nbr16; const TileDesc *tiles;
+    unsigned N, Np, nblk, r, W;
+    int tiled, s16, periodic;
+    float box[3], inv_box[3];
+    float dcut2, lim2;                  // lim2: largest squared displacement since the build for which the list still holds every pair within dcut
+    uint2 *out; unsigned long long cap;
+    unsigned long long *count;          // [0] pairs found, [1] != 0: some bead has moved too far (the caller rebuilds)
+};
+void gd_launch_pairs(const PairsP &p, hipStream_t st);
 void gd_launch_gather_xyz(const float4 *pos, const unsigned *slot_of, float *out, unsigned N, unsigned Np, unsigned R, int quantize,
                           hipStream_t st);
 void gd_launch_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np,

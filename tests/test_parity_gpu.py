@@ -122,6 +122,45 @@ def test_neighbor_search_pair_set(hip, oracle, box):
     assert len(ph) > 100
 
 
+def test_contact_pairs_from_the_resident_list(hip, oracle):
+    """Contact-map / glue search (simulation_interphase/contact_map.cc:31-91, glues/glue_simulator.cpp:41,67-77) served
+    from the Verlet list that is already on the device: S-genome-30k x 4 replicas, a few steps after a list build, search at
+    contactmap_distance 0.4 (> force cutoff 0.3, < list radius 0.525).  The pair SET equals the oracle's search over the
+    same positions, for every replica; no list build is spent while the beads have moved little, at most one when they
+    have moved far -- and the force list stays valid (the next run does not rebuild at its first step)."""
+    R = 4
+    s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
+    so = g.System(oracle, 30000, 1)
+    dt, kT = info["timestep"], info["temperature"]
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    s.set_tuning(rebuild_interval=12, adapt_interval=0)
+    s.begin_phase()
+    for steps, may_rebuild in ((2, 0), (9, 1)):
+        s.run(steps, dt, kT, seed=SEED, flags=flags)
+        rb0 = s.context().rebuilds
+        x = s.positions()
+        for r in range(R):
+            ph = {tuple(p) for p in s.search_pairs(0.4, replica=r)}
+            so.set_positions(x[r][None])
+            po = {tuple(p) for p in so.search_pairs(0.4)}
+            assert len(po) > 150000
+            for i, j in ph ^ po:       # only pairs within fp32 rounding of the search distance may differ
+                assert abs(np.linalg.norm(x[r][i] - x[r][j]) - 0.4) < 2e-6
+        c = s.context()
+        assert c.rebuilds - rb0 <= may_rebuild, (steps, rb0, c.rebuilds)
+        assert c.list_path == 2
+    # the list left behind is a valid force list: forces agree with the oracle, and running on does not rebuild at once
+    rb1 = s.context().rebuilds
+    s.run(1, dt, kT, seed=SEED, flags=flags)
+    assert s.context().rebuilds == rb1
+    so2, _ = wl.genome_interphase(oracle, n_beads=30000, n_replicas=1)
+    so2.set_positions(s.positions()[0][None])
+    c0 = s.context(0)
+    so2.set_context(0, c0.step, c0.bead_scale, c0.bond_scale, list(c0.semiaxes))
+    Fo = so2.forces()
+    assert np.abs(s.forces()[0] - Fo[0]).max() <= FORCE_RTOL * np.abs(Fo).max()
+
+
 def test_quantised_snapshot(hip):
     s = g.System(hip, 3, 1)
     x = np.array([[0.1234567, -3.7654321, 5.00000763], [1e-6, -1e-6, 0.5], [2.0000076, 7.99999, -7.99999]])
