@@ -71,7 +71,7 @@ class Context(C.Structure):
 class _RunDesc(C.Structure):
     _fields_ = [("temperature", C.c_double), ("timestep", C.c_double), ("spacestep", C.c_double),
                 ("steps", C.c_int64), ("seed", C.c_uint64), ("noise_mode", C.c_int32), ("flags", C.c_int32),
-                ("host_noise", C.POINTER(C.c_double))]
+                ("host_noise", C.POINTER(C.c_double)), ("replica_seeds", C.POINTER(C.c_uint64))]
 
 
 class Tuning(C.Structure):
@@ -306,11 +306,18 @@ class System:
         self.lib.check(self.lib.dll.gd_set_context(self._h, replica, step, bead_scale, bond_scale, s))
 
     # -- md::simulate_brownian_dynamics -----------------------------------------
-    def run(self, steps, timestep, temperature=1.0, seed=0, noise=NOISE_PHILOX, flags=0, host_noise=None, spacestep=0.0):
+    def run(self, steps, timestep, temperature=1.0, seed=0, noise=NOISE_PHILOX, flags=0, host_noise=None, spacestep=0.0,
+            replica_seeds=None):
         hn = None
         if host_noise is not None:
             hn = self._f64(host_noise, (steps, self.R, self.N, 3))
-        rd = _RunDesc(temperature, timestep, spacestep, steps, seed, noise, flags, _dptr(hn))
+        rs = None
+        if replica_seeds is not None:
+            rs = np.ascontiguousarray(replica_seeds, dtype=np.uint64)
+            if rs.shape != (self.R,):
+                raise ValueError(f"replica_seeds: expected shape ({self.R},)")
+        rd = _RunDesc(temperature, timestep, spacestep, steps, seed, noise, flags, _dptr(hn),
+                      None if rs is None else rs.ctypes.data_as(C.POINTER(C.c_uint64)))
         self.lib.check(self.lib.dll.gd_run(self._h, C.byref(rd)))
         return self.timing()
 

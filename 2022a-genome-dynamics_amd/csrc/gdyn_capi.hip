@@ -142,6 +142,7 @@ struct gd_system {
     DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part[2]; DevBuf<double> epart;   // react_part ping-pongs with ctx
     DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
     DevBuf<CtxF> ctxf;             // float context of the coming step (k_ctx -> k_step_p)
+    DevBuf<unsigned long long> seeds_d;     // gd_run_desc.replica_seeds of the run in progress
     // gd_search_pairs: device output, counters, and the cached result of the last call
     DevBuf<uint2> sp_out; DevBuf<unsigned long long> sp_count; std::vector<uint2> sp_host;
     bool sp_valid = false; uint32_t sp_r = 0; double sp_dcut = 0; uint64_t sp_serial = 0;
@@ -880,6 +881,12 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         HIPCHK(hipMemcpy(s->noise.p, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
     }
 
+    if (run->replica_seeds) {
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "seed width");
+        HIPCHK(s->seeds_d.resize(s->R, false));
+        HIPCHK(hipMemcpy(s->seeds_d.p, run->replica_seeds, s->R * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+
     int64_t done = 0;
     while (done < run->steps) {
         // ---- one verified chunk
@@ -912,6 +919,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             for (int64_t q = 0; q < n; q++) {
                 fill_common(s, p);
                 p.dt_d = run->timestep; p.dt = (float)run->timestep; p.kT = (float)run->temperature; p.seed = run->seed;
+                p.seeds = run->replica_seeds ? s->seeds_d.p : nullptr;
                 p.noise_mode = run->noise_mode; p.run_flags = run->flags;
                 p.host_noise = host_noise ? s->noise.p + (size_t)(done + k + q) * RN * 3 : nullptr;
                 // the interval adaptation needs the displacement at K steps since the build: recorded at the last force

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     if (MODE == GD_MODE_STEP && GD_ABL != 14 && (TILED || valid) && p.kT > 0.f) {
         if (p.noise_mode == NOISE_PHILOX) {
             const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
-            z = philox_normal3(p.seed, oid, step_now + 1, r);
+            z = p.seeds ? philox_normal3(p.seeds[r], oid, step_now + 1, 0u) : philox_normal3(p.seed, oid, step_now + 1, r);
         } else if (p.noise_mode == NOISE_HOST) {
             const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
             z = make_float3(h[0], h[1], h[2]);
@@ -987,7 +987,7 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
         // Brownian noise (role A), before the pair loop: independent of the tile
         float3 z = make_float3(0.f, 0.f, 0.f);
         if (role == 0 && valid && p.kT > 0.f) {
-            if (p.noise_mode == NOISE_PHILOX) z = philox_normal3(p.seed, oid, cx.step + 1, r);
+            if (p.noise_mode == NOISE_PHILOX) z = p.seeds ? philox_normal3(p.seeds[r], oid, cx.step + 1, 0u) : philox_normal3(p.seed, oid, cx.step + 1, r);
             else if (p.noise_mode == NOISE_HOST) {
                 const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
                 float zx = h[0], zy = h[1], zz = h[2];

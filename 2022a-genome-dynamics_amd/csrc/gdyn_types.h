@@ -173,6 +173,7 @@ struct StepParams {
     double dt_d;
     float dt, kT;
     unsigned long long seed;
+    const unsigned long long *seeds;    // [R] per-replica seeds (gd_run_desc.replica_seeds) or NULL
     int noise_mode, run_flags;
     const float *host_noise;            // (R, N, 3) normals of this step
     float rv;                           // list radius (violation check)

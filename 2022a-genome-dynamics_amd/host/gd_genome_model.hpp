@@ -17,7 +17,7 @@ namespace gd {
 inline void chk(int rc) { if (rc != GD_OK) throw std::runtime_error(gd_last_error()); }
 
 inline gd_system *build_genome_system(trajectory_store &store, simulation_config const &config, int device, bool loop_bonds,
-                                      bool mixed_chain_bonds, std::size_t &n_out)
+                                      bool mixed_chain_bonds, std::size_t &n_out, std::uint32_t n_replicas = 1)
 {
     auto const particles = store.load_particle_data();
     auto const chromosomes = store.load_chromosomes();
@@ -26,7 +26,7 @@ inline gd_system *build_genome_system(trajectory_store &store, simulation_config
     n_out = n;
     gd_system *sys = nullptr;
     gd_desc desc{};
-    desc.n_beads = (uint32_t)n; desc.n_replicas = 1; desc.device = device; desc.box_kind = GD_BOX_OPEN;
+    desc.n_beads = (uint32_t)n; desc.n_replicas = n_replicas; desc.device = device; desc.box_kind = GD_BOX_OPEN;
     chk(gd_create(&desc, &sys));
     try {
         // particles: a/b factors from the metadata, mobility per range

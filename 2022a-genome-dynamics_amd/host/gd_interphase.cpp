@@ -19,6 +19,7 @@
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -39,13 +40,13 @@ class contact_map {
 public:
     void set_contact_distance(double d) { _distance = d; }
     void clear() { _counts.clear(); }
-    void update(gd_system *sys)
+    void update(gd_system *sys, uint32_t replica)
     {
         if (!(_distance > 0)) return;     // the reference's default distance is 0 until the first callback set it
         uint64_t n = 0;
-        chk(gd_search_pairs(sys, 0, _distance, nullptr, 0, &n));
+        chk(gd_search_pairs(sys, replica, _distance, nullptr, 0, &n));       // (the library keeps the result for the fetch)
         _buffer.resize(2 * n);
-        if (n) chk(gd_search_pairs(sys, 0, _distance, _buffer.data(), n, &n));
+        if (n) chk(gd_search_pairs(sys, replica, _distance, _buffer.data(), n, &n));
         for (uint64_t k = 0; k < n; k++) _counts[{_buffer[2 * k], _buffer[2 * k + 1]}] += 1;
     }
     std::vector<std::array<std::uint32_t, 3>> accumulate() const
@@ -61,10 +62,15 @@ private:
     std::vector<std::uint32_t> _buffer;
 };
 
+// One driver = one libgdyn handle = R replicas = R trajectory files.  R = 1 is the reference program; R > 1 batches R runs
+// of the reference's ensemble (one process per seed, each with its own prepared file: 5-sim-genome/scripts/run_simulation:8-25,
+// read back as output-*.h5 by contact_map/contact_map.py:14-39) into one launch: replica r takes its initial structure, its
+// seeds and its outputs from file r; every replica draws the noise stream its own one-replica run would draw
+// (gd_run_desc.replica_seeds), so a batched trajectory equals the solo one up to fp32 summation order.
 class simulation_driver {
 public:
-    simulation_driver(gd::trajectory_store &store, int device)
-        : _store(store), _config(gd::parse_simulation_config(store.load_config_text())), _random(_config.interphase_seed)
+    simulation_driver(std::vector<std::unique_ptr<gd::trajectory_store>> &stores, int device)
+        : _stores(stores), _R(stores.size()), _config(gd::parse_simulation_config(stores[0]->load_config_text()))
     {
         // compatibility defaults of older runs (simulation_driver.cc:20-29)
         auto set_default = [](double &var, double def) { if (var == 0) var = def; };
@@ -72,6 +78,14 @@ public:
         set_default(_config.a_core_bond_length, _config.chromatin_bond_length);
         set_default(_config.b_core_bond_spring, _config.chromatin_bond_spring);
         set_default(_config.b_core_bond_length, _config.chromatin_bond_length);
+        for (std::size_t r = 0; r < _R; r++) {
+            auto const cfg = gd::parse_simulation_config(_stores[r]->load_config_text());
+            if (r > 0 && (cfg.interphase_steps != _config.interphase_steps || cfg.relaxation_steps != _config.relaxation_steps ||
+                          cfg.interphase_timestep != _config.interphase_timestep || cfg.interphase_sampling_interval != _config.interphase_sampling_interval ||
+                          cfg.a_core_diameter != _config.a_core_diameter || cfg.wall_mobility != _config.wall_mobility))
+                throw std::runtime_error("batched trajectories must share one simulation config (seeds aside)");
+            _random.emplace_back(cfg.interphase_seed);          // 1st draw: relaxation seed, 2nd: interphase seed
+        }
         setup(device);
     }
     ~simulation_driver() { gd_destroy(_sys); }
@@ -81,36 +95,57 @@ public:
 private:
     void setup(int device)
     {
-        _chromosomes = _store.load_chromosomes();
-        _sys = gd::build_genome_system(_store, _config, device, /*loop_bonds=*/true, /*mixed_chain_bonds=*/true, _n);
+        _sys = gd::build_genome_system(*_stores[0], _config, device, /*loop_bonds=*/true, /*mixed_chain_bonds=*/true, _n, (uint32_t)_R);
+        for (std::size_t r = 1; r < _R; r++) {
+            auto const p0 = _stores[0]->load_particle_data(), pr = _stores[r]->load_particle_data();
+            if (pr.size() != p0.size()) throw std::runtime_error("batched trajectories must hold the same model (bead count differs)");
+            for (std::size_t i = 0; i < p0.size(); i++)
+                if (pr[i].a != p0[i].a || pr[i].b != p0[i].b) throw std::runtime_error("batched trajectories must hold the same model (A/B factors differ)");
+        }
         // setup_context (simulation_driver.cc:43-51)
-        _context = gd::context{};
-        _context.wall_semiaxes[0] = _config.wall_init_semiaxes.x; _context.wall_semiaxes[1] = _config.wall_init_semiaxes.y;
-        _context.wall_semiaxes[2] = _config.wall_init_semiaxes.z;
-        _context.bead_scale = _config.bead_scale_init; _context.bond_scale = _config.bond_scale_init;
-        _buffer.resize(3 * _n);
+        gd::context c{};
+        c.wall_semiaxes[0] = _config.wall_init_semiaxes.x; c.wall_semiaxes[1] = _config.wall_init_semiaxes.y;
+        c.wall_semiaxes[2] = _config.wall_init_semiaxes.z;
+        c.bead_scale = _config.bead_scale_init; c.bond_scale = _config.bond_scale_init;
+        _context.assign(_R, c);
+        _contacts.resize(_R);
+        _buffer.resize(3 * _n * _R);
+        _energy.resize(_R);
+    }
+
+    std::vector<double> semiaxes() const
+    {
+        std::vector<double> v(3 * _R);
+        for (std::size_t r = 0; r < _R; r++) std::copy(_context[r].wall_semiaxes, _context[r].wall_semiaxes + 3, v.begin() + 3 * r);
+        return v;
     }
 
     void print_progress(char const *phase, long step)
     {
         std::time_t const now = std::time(nullptr);
-        double const radius = std::cbrt(_context.wall_semiaxes[0] * _context.wall_semiaxes[1] * _context.wall_semiaxes[2]);
-        std::clog << "[" << phase << "] " << std::put_time(std::localtime(&now), "%F %T") << '\t' << step << '\t'
-                  << "t: " << _context.time << '\t' << "R: " << radius << '\t' << "E: " << _context.mean_energy << '\n';
+        for (std::size_t r = 0; r < _R; r++) {
+            auto const &c = _context[r];
+            double const radius = std::cbrt(c.wall_semiaxes[0] * c.wall_semiaxes[1] * c.wall_semiaxes[2]);
+            std::clog << "[" << phase;
+            if (_R > 1) std::clog << ":" << r;
+            std::clog << "] " << std::put_time(std::localtime(&now), "%F %T") << '\t' << step << '\t'
+                      << "t: " << c.time << '\t' << "R: " << radius << '\t' << "E: " << c.mean_energy << '\n';
+        }
     }
 
     void mean_energy()
     {
-        double e = 0;
-        chk(gd_compute_energy(_sys, GD_TERM_ALL, &e));
-        _context.mean_energy = e / (double)_n;
+        chk(gd_compute_energy(_sys, GD_TERM_ALL, _energy.data()));
+        for (std::size_t r = 0; r < _R; r++) _context[r].mean_energy = _energy[r] / (double)_n;
     }
 
     void save_snapshot(long step)
     {
         chk(gd_get_positions_f32(_sys, _buffer.data(), /*quantize=*/1));      // 16 fractional bits, rounded on the device
-        _store.save_positions(step, _buffer.data(), _n);
-        _store.save_context(step, _context);
+        for (std::size_t r = 0; r < _R; r++) {
+            _stores[r]->save_positions(step, _buffer.data() + 3 * _n * r, _n);
+            _stores[r]->save_context(step, _context[r]);
+        }
     }
 
     // advance to `target`, stopping one step early to capture the context the reference's callback(target) sees:
@@ -118,23 +153,27 @@ private:
     void advance(gd_run_desc &run, long &step, long target)
     {
         if (target - step > 1) { run.steps = target - step - 1; chk(gd_run(_sys, &run)); }
-        gd_context ctx;
-        chk(gd_get_context(_sys, 0, &ctx));
-        _context.bead_scale = ctx.bead_scale; _context.bond_scale = ctx.bond_scale;
-        std::copy(ctx.semiaxes, ctx.semiaxes + 3, _context.wall_semiaxes);
+        for (std::size_t r = 0; r < _R; r++) {
+            gd_context ctx;
+            chk(gd_get_context(_sys, (uint32_t)r, &ctx));
+            _context[r].bead_scale = ctx.bead_scale; _context[r].bond_scale = ctx.bond_scale;
+            std::copy(ctx.semiaxes, ctx.semiaxes + 3, _context[r].wall_semiaxes);
+        }
         if (target > step) { run.steps = 1; chk(gd_run(_sys, &run)); }
         step = target;
     }
 
     void run_relaxation()
     {
-        _store.set_phase("relaxation");
-        auto const init = _store.load_positions(0);
-        if (init.size() != _n) throw std::runtime_error("relaxation/0/positions has the wrong number of beads");
-        std::vector<double> xyz(3 * _n);
-        for (std::size_t i = 0; i < _n; i++) for (int k = 0; k < 3; k++) xyz[3 * i + k] = init[i][k];
+        std::vector<double> xyz(3 * _n * _R);
+        for (std::size_t r = 0; r < _R; r++) {
+            _stores[r]->set_phase("relaxation");
+            auto const init = _stores[r]->load_positions(0);
+            if (init.size() != _n) throw std::runtime_error("relaxation/0/positions has the wrong number of beads");
+            for (std::size_t i = 0; i < _n; i++) for (int k = 0; k < 3; k++) xyz[3 * (_n * r + i) + k] = init[i][k];
+        }
         chk(gd_set_positions(_sys, xyz.data()));
-        chk(gd_begin_phase(_sys, _context.wall_semiaxes));
+        chk(gd_begin_phase(_sys, semiaxes().data()));
         auto callback = [&](long step) {
             bool const logging = step % _config.relaxation_logging_interval == 0, sampling = step % _config.relaxation_sampling_interval == 0;
             if (logging || sampling) mean_energy();
@@ -142,9 +181,12 @@ private:
             if (sampling) save_snapshot(step);
         };
         callback(0);
+        std::vector<uint64_t> seeds(_R);
+        for (std::size_t r = 0; r < _R; r++) seeds[r] = _random[r]();
         gd_run_desc run{};
         run.temperature = _config.relaxation_temperature; run.timestep = _config.relaxation_timestep;
-        run.spacestep = _config.relaxation_spacestep; run.seed = _random(); run.noise_mode = GD_NOISE_PHILOX; run.flags = 0;
+        run.spacestep = _config.relaxation_spacestep; run.seed = seeds[0]; run.noise_mode = GD_NOISE_PHILOX; run.flags = 0;
+        run.replica_seeds = _R > 1 ? seeds.data() : nullptr;
         long step = 0;
         while (step < _config.relaxation_steps) {
             long const next = std::min<long>(_config.relaxation_steps, std::min(next_multiple(step, _config.relaxation_logging_interval),
@@ -158,39 +200,50 @@ private:
 
     void run_simulation()
     {
-        _store.set_phase("interphase");
+        for (auto &st : _stores) st->set_phase("interphase");
         double const dt = _config.interphase_timestep;
-        chk(gd_begin_phase(_sys, _context.wall_semiaxes));       // step = 0, time = 0
-        gd_context last;
-        chk(gd_get_context(_sys, 0, &last));
-        double reaction[3] = {last.axial_reaction[0], last.axial_reaction[1], last.axial_reaction[2]};
+        chk(gd_begin_phase(_sys, semiaxes().data()));       // step = 0, time = 0
+        std::vector<std::array<double, 3>> reaction(_R);
+        for (std::size_t r = 0; r < _R; r++) {
+            gd_context last;
+            chk(gd_get_context(_sys, (uint32_t)r, &last));
+            reaction[r] = {last.axial_reaction[0], last.axial_reaction[1], last.axial_reaction[2]};
+        }
 
         // host part of callback(step): everything except the state updates that run on the device
         auto observe = [&](long step) {
-            _context.time = (double)step * dt;
+            for (auto &c : _context) c.time = (double)step * dt;
             bool const logging = step % _config.interphase_logging_interval == 0, sampling = step % _config.interphase_sampling_interval == 0;
             long const frame = step / _config.interphase_sampling_interval;
             if (logging || sampling) mean_energy();
             if (logging) print_progress("inter", step);
             if (sampling) save_snapshot(step);
-            if (step % _config.contactmap_update_interval == 0) _contacts.update(_sys);
-            if (sampling && frame % _config.contactmap_thinning_rate == 0) { _store.save_contacts(step, _contacts.accumulate()); _contacts.clear(); }
+            if (step % _config.contactmap_update_interval == 0)
+                for (std::size_t r = 0; r < _R; r++) _contacts[r].update(_sys, (uint32_t)r);
+            if (sampling && frame % _config.contactmap_thinning_rate == 0)
+                for (std::size_t r = 0; r < _R; r++) { _stores[r]->save_contacts(step, _contacts[r].accumulate()); _contacts[r].clear(); }
         };
 
         // callback(0): observation, then update_bead_scale() and update_wall_semiaxes() on the host
         // (simulation_driver_interphase.cc:42-43,59-80); the packing reaction is that of the last force evaluation
         observe(0);
-        _context.bead_scale = 1 - (1 - _config.bead_scale_init) * std::exp(-0.0 / _config.bead_scale_tau);
-        _context.bond_scale = 1 - (1 - _config.bond_scale_init) * std::exp(-0.0 / _config.bond_scale_tau);
-        _contacts.set_contact_distance(_config.contactmap_distance * _context.bead_scale);
         double const spring[3] = {_config.wall_semiaxes_spring.x, _config.wall_semiaxes_spring.y, _config.wall_semiaxes_spring.z};
-        for (int k = 0; k < 3; k++)
-            _context.wall_semiaxes[k] += dt * _config.wall_mobility * (reaction[k] - spring[k] * _context.wall_semiaxes[k]);
-        chk(gd_set_context(_sys, 0, 0, _context.bead_scale, _context.bond_scale, _context.wall_semiaxes));
+        for (std::size_t r = 0; r < _R; r++) {
+            auto &c = _context[r];
+            c.bead_scale = 1 - (1 - _config.bead_scale_init) * std::exp(-0.0 / _config.bead_scale_tau);
+            c.bond_scale = 1 - (1 - _config.bond_scale_init) * std::exp(-0.0 / _config.bond_scale_tau);
+            _contacts[r].set_contact_distance(_config.contactmap_distance * c.bead_scale);
+            for (int k = 0; k < 3; k++)
+                c.wall_semiaxes[k] += dt * _config.wall_mobility * (reaction[r][k] - spring[k] * c.wall_semiaxes[k]);
+            chk(gd_set_context(_sys, (uint32_t)r, 0, c.bead_scale, c.bond_scale, c.wall_semiaxes));
+        }
 
+        std::vector<uint64_t> seeds(_R);
+        for (std::size_t r = 0; r < _R; r++) seeds[r] = _random[r]();
         gd_run_desc run{};
         run.temperature = _config.interphase_temperature; run.timestep = dt; run.spacestep = _config.interphase_spacestep;
-        run.seed = _random(); run.noise_mode = GD_NOISE_PHILOX; run.flags = GD_RUN_UPDATE_SCALES | GD_RUN_WALL_DYNAMICS;
+        run.seed = seeds[0]; run.noise_mode = GD_NOISE_PHILOX; run.flags = GD_RUN_UPDATE_SCALES | GD_RUN_WALL_DYNAMICS;
+        run.replica_seeds = _R > 1 ? seeds.data() : nullptr;
         long step = 0;
         while (step < _config.interphase_steps) {
             long const next = std::min<long>(_config.interphase_steps,
@@ -200,34 +253,50 @@ private:
             advance(run, step, next);
             observe(step);
             // the contact distance for later updates is the one set at the end of this callback
-            gd_context ctx;
-            chk(gd_get_context(_sys, 0, &ctx));
-            _contacts.set_contact_distance(_config.contactmap_distance * ctx.bead_scale);
+            for (std::size_t r = 0; r < _R; r++) {
+                gd_context ctx;
+                chk(gd_get_context(_sys, (uint32_t)r, &ctx));
+                _contacts[r].set_contact_distance(_config.contactmap_distance * ctx.bead_scale);
+            }
         }
     }
 
-    gd::trajectory_store &_store;
+    std::vector<std::unique_ptr<gd::trajectory_store>> &_stores;
+    std::size_t _R;
     gd::simulation_config _config;
-    gd::context _context;
-    contact_map _contacts;
-    std::mt19937_64 _random;     // 1st draw: relaxation seed, 2nd: interphase seed
+    std::vector<gd::context> _context;
+    std::vector<contact_map> _contacts;
+    std::vector<std::mt19937_64> _random;
     gd_system *_sys = nullptr;
-    std::vector<gd::chromosome_range> _chromosomes;
     std::size_t _n = 0;
     std::vector<float> _buffer;
+    std::vector<double> _energy;
 };
 
 }  // namespace
 
 int main(int argc, char **argv)
 {
-    if (argc < 2 || argc > 3) {
-        std::cerr << "usage: gd_interphase <trajectory> [device]\n";
+    // gd_interphase <trajectory> [device]                      the reference's command line
+    // gd_interphase [--device d] <trajectory> <trajectory>...  R prepared files as R replicas of one handle
+    std::vector<std::string> files;
+    int device = 0;
+    for (int i = 1; i < argc; i++) {
+        std::string const arg = argv[i];
+        if (arg == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
+        else files.push_back(arg);
+    }
+    if (files.size() == 2 && !files[1].empty() && files[1].find_first_not_of("0123456789") == std::string::npos) {
+        device = std::stoi(files[1]); files.pop_back();
+    }
+    if (files.empty()) {
+        std::cerr << "usage: gd_interphase <trajectory> [device]\n       gd_interphase [--device d] <trajectory> <trajectory>...\n";
         return 1;
     }
     try {
-        gd::trajectory_store store{argv[1]};
-        simulation_driver driver{store, argc == 3 ? std::stoi(argv[2]) : 0};
+        std::vector<std::unique_ptr<gd::trajectory_store>> stores;
+        for (auto const &f : files) stores.push_back(std::make_unique<gd::trajectory_store>(f));
+        simulation_driver driver{stores, device};
         driver.run();
     } catch (std::exception const &e) {
         std::cerr << "error: " << e.what() << '\n';

@@ -245,10 +245,14 @@ typedef struct {
     double   timestep;
     double   spacestep;     /* must be 0 (all reference defaults, config_entries.inc:61,71,79) */
     int64_t  steps;
-    uint64_t seed;          /* replica r draws from stream (seed, r) */
+    uint64_t seed;          /* replica r draws from stream (seed, r); see replica_seeds */
     int32_t  noise_mode;
     int32_t  flags;
     const double *host_noise;   /* GD_NOISE_HOST: (steps, R, N, 3) standard normals */
+    const uint64_t *replica_seeds;  /* optional (R): replica r draws from stream (replica_seeds[r], 0) -- the stream a
+                                       one-replica run with seed replica_seeds[r] uses -- instead of (seed, r); this is
+                                       how R runs of the reference's one-process-per-seed ensemble
+                                       (5-sim-genome/scripts/run_simulation:8-25) are batched into one handle */
 } gd_run_desc;
 
 int gd_run(gd_system *sys, const gd_run_desc *run);

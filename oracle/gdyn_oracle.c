@@ -914,7 +914,7 @@ int gd_run(gd_system *s, const gd_run_desc *run)
     double dt = run->timestep, kT = run->temperature;
     double *F = xcalloc((size_t)N * 3, sizeof(double));
     mt64_t *mt = NULL;
-    if (run->noise_mode == GD_NOISE_MT19937) { mt = xcalloc(R, sizeof *mt); for (uint32_t r = 0; r < R; r++) mt64_seed(&mt[r], run->seed + r); }
+    if (run->noise_mode == GD_NOISE_MT19937) { mt = xcalloc(R, sizeof *mt); for (uint32_t r = 0; r < R; r++) mt64_seed(&mt[r], run->replica_seeds ? run->replica_seeds[r] : run->seed + r); }
     for (int64_t k = 1; k <= run->steps; k++) {
         for (uint32_t r = 0; r < R; r++) {
             ctx_t *c = &s->ctx[r];
@@ -925,7 +925,10 @@ int gd_run(gd_system *s, const gd_run_desc *run)
             for (uint32_t i = 0; i < N; i++) {
                 double mu_dt = s->mob[i] * dt, z[3] = { 0, 0, 0 };
                 if (kT > 0) switch (run->noise_mode) {
-                    case GD_NOISE_PHILOX: philox_normal3(run->seed, i, gstep, r, z); break;
+                    case GD_NOISE_PHILOX:
+                        if (run->replica_seeds) philox_normal3(run->replica_seeds[r], i, gstep, 0, z);      /* the stream of a one-replica run with that seed */
+                        else philox_normal3(run->seed, i, gstep, r, z);
+                        break;
                     case GD_NOISE_HOST: { const double *h = run->host_noise + (((size_t)(k - 1) * R + r) * N + i) * 3; z[0] = h[0]; z[1] = h[1]; z[2] = h[2]; break; }
                     case GD_NOISE_MT19937: z[0] = mt64_normal(&mt[r]); z[1] = mt64_normal(&mt[r]); z[2] = mt64_normal(&mt[r]); break;
                     default: break;

@@ -51,13 +51,15 @@ def _config(radius):
 NUC = (540, 600)           # nucleolar particles of the droplet variant: the last 60 beads; bonded to "NOR" beads 100..159
 
 
-def _inputs(tmp, droplet=False):
+def _inputs(tmp, droplet=False, seed=None, walk_seed=8):
     rng = np.random.default_rng(7)
     lens = wl.chain_lengths(N)
     a, b = wl.ab_types(N, rng)
     radius = 0.27 * (N / (8 * 0.3)) ** (1 / 3)
-    x0 = wl.confined_random_walks(lens, radius, 0.2, np.random.default_rng(8))
+    x0 = wl.confined_random_walks(lens, radius, 0.2, np.random.default_rng(walk_seed))
     cfg = _config(radius)
+    if seed is not None:
+        cfg["interphase_seed"] = seed
     if droplet:
         cfg.update(nucleolus_droplet_energy=0.6, nucleolus_droplet_decay=0.2, nucleolus_droplet_cutoff=0.4, nucleolus_mobility=0.7,
                    nucleolus_bond_spring=5.0, nucleolus_bond_length=0.1)
@@ -246,6 +248,78 @@ def test_missing_config_key_is_an_error(tmp_path, oracle):
 @pytest.mark.parametrize("droplet", [False, True])
 def test_driver_on_gpu(tmp_path, hip, oracle, droplet):
     _check_run(tmp_path, oracle, oracle, _make("gd_interphase", ".", "../csrc", "gdyn"), atol=2e-4, droplet=droplet)
+
+
+def _batch_case(tmp):
+    """Three prepared trajectory files of one ensemble: same model, their own seeds and initial structures."""
+    dirs = []
+    for k in range(3):
+        d = tmp / f"run{k}"
+        d.mkdir()
+        _inputs(d, seed=12345 + k, walk_seed=8 + k)
+        dirs.append(d)
+    return dirs
+
+
+def _frames(d):
+    out = {}
+    for phase in ("relaxation", "interphase"):
+        for step in _tool("steps", d / "traj.h5", phase).split():
+            out[(phase, int(step))] = (_positions(d, phase, step), json.loads(_tool("context", d / "traj.h5", phase, step)),
+                                       _tool("contacts", d / "traj.h5", phase, step) if phase == "interphase" else "")
+    return out
+
+
+def test_batched_driver_equals_solo_runs_on_oracle(tmp_path, oracle):
+    """gd_interphase run0.h5 run1.h5 run2.h5 (three replicas of one handle, reference ensemble model:
+    5-sim-genome/scripts/run_simulation:8-25) writes into every file exactly what the one-file program writes: each
+    replica draws its own run's noise stream (gd_run_desc.replica_seeds).  On the fp64 oracle: bit for bit."""
+    drv = _make_oracle("gd_interphase", tmp_path)
+    env = _env(os.path.join(ROOT, "oracle"))
+    solo = _batch_case(tmp_path / "solo") if (tmp_path / "solo").mkdir() is None else None
+    batch = _batch_case(tmp_path / "batch") if (tmp_path / "batch").mkdir() is None else None
+    for d in solo:
+        subprocess.run([str(drv), str(d / "traj.h5")], check=True, capture_output=True, env=env)
+    log = subprocess.run([str(drv), *[str(d / "traj.h5") for d in batch]], check=True, capture_output=True, text=True, env=env)
+    assert sum(ln.startswith("[inter:2]") for ln in log.stderr.splitlines()) == INTER // 10 + 1
+    for ds, db in zip(solo, batch):
+        fs, fb = _frames(ds), _frames(db)
+        assert fs.keys() == fb.keys() and len(fs) == 7
+        for key in fs:
+            assert np.array_equal(fs[key][0], fb[key][0]), key
+            assert fs[key][1] == fb[key][1] and fs[key][2] == fb[key][2], key
+    assert not np.array_equal(_frames(batch[0])[("interphase", 60)][0], _frames(batch[1])[("interphase", 60)][0])
+
+
+def test_farm_launcher_splits_files_over_gpus(tmp_path):
+    subprocess.check_call(["make", "-s", "-C", HOST, "gd_farm"])
+    files = [f"out-{k}.h5" for k in range(5)]
+    r = subprocess.run([os.path.join(HOST, "gd_farm"), "--gpus", "2", "--dry-run", "gd_interphase", *files], capture_output=True, text=True)
+    assert r.returncode == 0
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[farm]")]
+    assert lines == ["[farm] gpu 0: gd_interphase --device 0 out-0.h5 out-1.h5 out-2.h5", "[farm] gpu 1: gd_interphase --device 1 out-3.h5 out-4.h5"]
+    # a real launch: two groups, the children run and their status comes back
+    ok = subprocess.run([os.path.join(HOST, "gd_farm"), "--gpus", "2", "true", "a", "b"], capture_output=True, text=True)
+    bad = subprocess.run([os.path.join(HOST, "gd_farm"), "--gpus", "2", "false", "a", "b"], capture_output=True, text=True)
+    assert ok.returncode == 0 and bad.returncode == 1
+
+
+@pytest.mark.gpu
+def test_batched_driver_on_gpu(tmp_path, hip, oracle):
+    """The libgdyn-linked program batching three files on the MI355X against the ORACLE-linked one-file program."""
+    drv_o = _make_oracle("gd_interphase", tmp_path)
+    drv_h = _make("gd_interphase", ".", "../csrc", "gdyn")
+    (tmp_path / "solo").mkdir(); (tmp_path / "batch").mkdir()
+    solo, batch = _batch_case(tmp_path / "solo"), _batch_case(tmp_path / "batch")
+    for d in solo:
+        subprocess.run([str(drv_o), str(d / "traj.h5")], check=True, capture_output=True, env=_env(os.path.join(ROOT, "oracle")))
+    subprocess.run([str(drv_h), "--device", "0", *[str(d / "traj.h5") for d in batch]], check=True, capture_output=True)
+    for ds, db in zip(solo, batch):
+        fs, fb = _frames(ds), _frames(db)
+        assert fs.keys() == fb.keys()
+        for key in fs:
+            assert np.abs(fs[key][0] - fb[key][0]).max() <= 2e-4, key
+            assert np.allclose(fs[key][1]["wall_semiaxes"], fb[key][1]["wall_semiaxes"], rtol=0, atol=1e-7)
 
 
 # ---------------------------------------------------------------------------------------------- gd_spindle
