@@ -143,6 +143,9 @@ struct gd_system {
     DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
     DevBuf<CtxF> ctxf;             // float context of the coming step (k_ctx -> k_step_p)
     DevBuf<unsigned long long> seeds_d;     // gd_run_desc.replica_seeds of the run in progress
+    DevBuf<unsigned> dmax;          // [R] largest squared displacement since the list build (k_step keeps it; zeroed by the build)
+    float rn = 0;                   // near-class radius of the tiled list in use
+    double near_frac = 0.65;        // near-class radius = cutoff + near_frac x (list radius - cutoff)
     // gd_search_pairs: device output, counters, and the cached result of the last call
     DevBuf<uint2> sp_out; DevBuf<unsigned long long> sp_count; std::vector<uint2> sp_host;
     bool sp_valid = false; uint32_t sp_r = 0; double sp_dcut = 0; uint64_t sp_serial = 0;
@@ -185,6 +188,8 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; }   // wall_semiaxes {0,0,0} until a wall is set (simulation_context.hpp:16)
     s->lcount.assign(s->R, 0ull);
     s->ncell_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8ull * s->N, 4096ull), 262144ull);
+    if (const char *e = dev_env("GDYN_NEAR_FRAC")) s->near_frac = atof(e);
+    if (const char *e = dev_env("GDYN_SKIN")) s->skin = atof(e);
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(GD_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     const size_t RNp = (size_t)s->R * s->Np, RN = (size_t)s->R * s->N;
@@ -199,7 +204,7 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
-         s->lcount_d.resize(s->R) == hipSuccess && s->ctxf.resize(s->R) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
+         s->lcount_d.resize(s->R) == hipSuccess && s->ctxf.resize(s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess;
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
@@ -680,7 +685,8 @@ static void fill_common(gd_system *s, StepParams &p)
         for (int k = 0; k < 3; k++) p.ps[q].p[k] = (float)s->psrc[q].p[k];
     }
     p.has_bend = s->has_bend; p.has_bonds = s->has_bonds;
-    p.rv = s->rv; p.term_mask = GD_TERM_ALL;
+    p.rv = s->rv; p.rn = s->rn; p.dmax = s->dmax.p; p.term_mask = GD_TERM_ALL;
+    if (dev_env("GDYN_FORCE_FAR")) p.rn = 0.f;      // (timing experiments: the far class in every step)
     p.fout = s->fout.p; p.epart = s->epart.p;
 }
 
@@ -694,7 +700,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
 {
     const bool tiled = with_list && allow_tiled && want_tiled(s);
     if (with_list) {
-        if (s->W == 0) s->W = 64;
+        if (s->W == 0) s->W = 96;      // (tiled lists pad the near and the far class to whole chunks separately)
         s->W = (s->W + GD_UNROLL - 1) & ~(GD_UNROLL - 1);
         const size_t need = (size_t)s->W * s->R * s->Np;   // entries; chunked wave-interleaved layout (k_step)
         // (grown on demand, given back when a dense transient has passed)
@@ -707,7 +713,11 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.N = s->N; b.Np = s->Np; b.R = s->R; b.nblk = s->nblk; b.stride = (size_t)s->R * s->Np;
     b.periodic = s->box_kind == GD_BOX_PERIODIC;
     for (int k = 0; k < 3; k++) { b.box[k] = (float)s->box[k]; b.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
-    b.rv = rv; b.ncell_cap = s->ncell_cap;
+    b.rv = rv; b.ncell_cap = s->ncell_cap; b.dmax = s->dmax.p;
+    {   // near-class radius: the (look-ahead) cutoff the list radius was derived from, plus a share of the skin
+        const float cutb = rv - (float)(pair_cutoff(s) * s->skin);
+        b.rn = (cutb > 0.f && cutb < rv) ? cutb + (float)s->near_frac * (rv - cutb) : rv;
+    }
     b.pos_in = s->pos[s->pcur].p; b.pos_out = s->pos[s->pcur ^ 1].p; b.xb = s->xb.p;
     b.orig_in = s->orig[s->ocur].p; b.orig_out = s->orig[s->ocur ^ 1].p; b.slot_of = s->slot_of.p;
     b.cell_id = s->cell_id.p; b.rank = s->rank.p; b.cell_cnt = s->cell_cnt.p; b.cell_start = s->cell_start.p;
@@ -723,7 +733,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     gd_launch_build(b, s->stream);
     s->list_tiled = tiled; s->list_tile_cap = s->tile_cap;
     s->pcur ^= 1; s->ocur ^= 1;
-    s->rv = rv; s->steps_since_build = 0; s->rebuilds++;
+    s->rv = rv; s->rn = b.rn; s->steps_since_build = 0; s->rebuilds++;
     s->timing.rebuild_launches++;
     return GD_OK;
 }
@@ -787,7 +797,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
     else if (!tover && need_w > 0) {
         // the longest list is reported by every build: give the row width back when a dense transient has passed
-        const unsigned want_w = std::max(32u, (need_w + need_w / 4 + 8 + GD_UNROLL - 1) & ~(GD_UNROLL - 1));
+        const unsigned want_w = std::max(64u, (need_w + need_w / 4 + 16 + GD_UNROLL - 1) & ~(GD_UNROLL - 1));
         if (2 * want_w <= s->W) s->W = want_w;       // (takes effect at the next build; the list in use keeps list_W)
     }
     if (tover && dev_env("GDYN_DEBUG")) {

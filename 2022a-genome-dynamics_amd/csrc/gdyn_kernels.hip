@@ -283,7 +283,8 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
 // S16 (tiled lists only): entries are BYTE offsets into the tile (tile capacity < 4096 entries), one decode
 // instruction per entry instead of mask + shift-add
 template <int MODE, bool PERIODIC, bool TILED, int PK, bool S16>
-__global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
+__global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) void k_step(const StepParams p)      // tiled stepping: three
+                                                                                     // blocks per CU = 6 waves per SIMD = at most 80 VGPRs
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ BondType s_bt[GD_MAX_BOND_TYPES];
@@ -306,6 +307,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     // stay scalar loads; wave 0 also starts its full-context and reaction-partial loads first
     const long long ctx_step0 = p.ctx_in[r].step;
     const int ctx_pending0 = p.ctx_in[r].pending;
+    // largest squared displacement of any bead of the replica since the list build, as of the positions this step reads
+    // (kept by the previous steps): decides whether the far class of the lists can matter in this step
+    const float dmax0 = (MODE == GD_MODE_STEP && TILED) ? __uint_as_float(p.dmax[r * GD_DMAX_STRIDE]) : 0.f;
     // ---- prologue (tiled path), ordered for the IN-ORDER vmcnt counter:
     //   1. the thread's (meta, bead id) record -- the one per-bead value the noise needs -- and the tile descriptor
     //      (scalar loads: after a DMA the compiler would turn them into per-lane vector loads); both waited for here;
@@ -377,17 +381,17 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
         if (p.has_bonds) adj0 = adj[0];
         if (p.pair.enabled) { qa = lst[0]; qb = lst[64]; }
     }
-    unsigned local = GD_REC_NONE;      // tiled: block-local slot of the thread's bead (GD_REC_NONE: the thread has none)
+    unsigned local = 0, nA = 0, nB = 0;      // tiled: block-local slot of the thread's bead, chunks of the near and far class
     if (TILED) {
-        local = (mo.x >> 12) & 0x3ffu;
-        meta = (mo.x & 0xfffu) | ((mo.x >> 22) << 16);       // the generic layout: degree | point-source mask << 8 | length << 16
+        local = (mo.x >> 12) & 0x1ffu; nA = (mo.x >> 21) & 31u; nB = (mo.x >> 26) & 31u;
+        meta = mo.x & 0xfffu;                    // degree | point-source mask << 8 (the generic layout without the length)
         oid = mo.y;
     }
     // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
     // and the per-bead loads are in flight (the step index comes from a uniform scalar load).  Tiled path: whether the
     // thread owns a bead is not known yet (that is in the build-position record); threads without one have bead id 0.
     float3 z = make_float3(0.f, 0.f, 0.f);
-    if (MODE == GD_MODE_STEP && GD_ABL != 14 && (TILED || valid) && p.kT > 0.f) {
+    if (MODE == GD_MODE_STEP && GD_ABL != 14 && (TILED ? oid != GD_REC_NOBEAD : valid) && p.kT > 0.f) {
         if (p.noise_mode == NOISE_PHILOX) {
             const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
             z = p.seeds ? philox_normal3(p.seeds[r], oid, step_now + 1, 0u) : philox_normal3(p.seed, oid, step_now + 1, r);
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     __syncthreads();
     GD_STAMP(1);      // barrier (tile arrival)
     if (TILED) {
-        valid = local != GD_REC_NONE;
+        valid = oid != GD_REC_NOBEAD;
         slot = valid ? blk * GD_BLOCK + local : p.N;
         g = rbase + slot;
         if (valid) {
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     float3 F = make_float3(0.f, 0.f, 0.f);
     float3 react = make_float3(0.f, 0.f, 0.f);
     float E = 0.f;
-    float disp2 = 0.f;
+    float disp2 = 0.f, dnew2 = 0.f;
 
     if (valid) {
         const float3 xi = make_float3(xi4.x, xi4.y, xi4.z);
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                 const float lim = 0.5f * (p.rv - cut);
                 if (!(lim > 0.f) || disp2 > lim * lim) p.flags[r * GD_NFLAGS + GD_FLAG_VIOLATION] = 1u;
             }
-            const unsigned cnt = meta >> 16;
+            const unsigned cnt = meta >> 16;             // generic path: exact length (tiled: chunk counts nA, nB)
             // Pair lists are stored in chunks of 16 bytes per bead, wave-interleaved:
             // chunk c of bead g is uint4 #((g/64)*NC + c)*64 + g%64  (one coalesced 1 KiB read per wave).
             // Tiled: 8 x u16 tile indices per chunk; generic: 4 x u32 slots per chunk.
@@ -462,15 +466,23 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             // The list is padded to a multiple of GD_UNROLL with the bead's own index (zero
             // displacement => zero force), so every batch issues its index loads and its
             // neighbour reads together and the loop body has no bounds test.
-            const unsigned cntp = (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
+            // Tiled lists: near class in chunks 0 .. nA-1, far class in chunks NCL-1 .. NCL-nB.  The far class was at least
+            // rn away at the build: it can only matter once cutoff + 2 x largest displacement exceeds rn (wave-uniform
+            // test on the replica's running maximum; force / energy evaluations always take both classes).
+            bool use_far = true;
+            if (MODE == GD_MODE_STEP && TILED) { const float h = 0.5f * (p.rn - cut); use_far = !(h > 0.f) || dmax0 > h * h; }
+            const unsigned nch = TILED ? nA + (use_far ? nB : 0u) : 0u;
+            const unsigned cntp = TILED ? nch * GD_UNROLL : (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
+            const unsigned self_e = TILED ? (S16 ? (own_base + local) << 4 : own_base + local) : 0u;     // the padding entries (energy mode skips them)
             // software pipeline: the chunk(s) of the next batch are in flight while one is processed
             // (a second batch of look-ahead bought nothing and costs the registers of one occupancy step)
+            if (TILED && nA == 0u && nch != 0u) qa = nt_load(&lst[(size_t)(NCL - 1u) * 64]);      // (no near chunk: the first one is a far chunk)
             for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
                 unsigned jj[GD_UNROLL];
                 float4 xjv[GD_UNROLL];
                 const uint4 q = qa, q0 = qa, q1 = qb;
                 if (k0 + GD_UNROLL < cntp) {
-                    if (TILED) qa = nt_load(&lst[(size_t)(k0 / 8 + 1) * 64]);
+                    if (TILED) { const unsigned c1 = k0 / 8 + 1; qa = nt_load(&lst[(size_t)(c1 < nA ? c1 : NCL - 1u - (c1 - nA)) * 64]); }
                     else { qa = lst[(size_t)(k0 / 4 + 2) * 64]; qb = lst[(size_t)(k0 / 4 + 3) * 64]; }
                 }
                 if (TILED) {
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                         const float f = GD_ABL == 21 ? waca * fmaxf(fmaf(-r2, inv_sa2, 1.0f), 0.0f)
                                       : GD_ABL == 24 ? r2 : softcore_2383(r2, inv_sa2, inv_sb2, waca, wbcb);
                         F.x = fmaf(f, d.x, F.x); F.y = fmaf(f, d.y, F.y); F.z = fmaf(f, d.z, F.z);
-                        if (MODE == GD_MODE_ENERGY && k0 + u < cnt)
+                        if (MODE == GD_MODE_ENERGY && (TILED ? j != self_e : k0 + u < cnt))
                             E += 0.5f * softcore_2383_energy(r2, inv_sa2, inv_sb2, p.pair.eps_a, p.pair.eps_b, wa, wb);
                     } else if (r2 < cut2) {
                         if (mix) {
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
                         softcore(p.pair.eps_b, inv_sb2, p.pair.p_b, p.pair.q_b, r2, eb, fb);
                         const float f = wa * fa + wb * fb;
                         F.x += f * d.x; F.y += f * d.y; F.z += f * d.z;
-                        if (MODE == GD_MODE_ENERGY && k0 + u < cnt) E += 0.5f * (wa * ea + wb * eb);
+                        if (MODE == GD_MODE_ENERGY && (TILED ? j != self_e : k0 + u < cnt)) E += 0.5f * (wa * ea + wb * eb);
                     }
                 }
             }
@@ -699,8 +711,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
             const float mu_dt = mu * p.dt;
             const float sg = sqrtf(2.0f * p.kT * mu_dt);
-            p.pos_out[g] = make_float4(xi.x + mu_dt * F.x + sg * z.x, xi.y + mu_dt * F.y + sg * z.y,
-                                       xi.z + mu_dt * F.z + sg * z.z, xi4.w);
+            const float ex = mu_dt * F.x + sg * z.x, ey = mu_dt * F.y + sg * z.y, ez = mu_dt * F.z + sg * z.z;
+            p.pos_out[g] = make_float4(xi.x + ex, xi.y + ey, xi.z + ez, xi4.w);
+            // displacement of the NEW position since the build, bounded by the triangle inequality (the build position
+            // need not stay in registers): |x + dx - x0| <= |x - x0| + |dx|
+            if (TILED) { const float dn = __builtin_amdgcn_sqrtf(disp2) + __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez); dnew2 = dn * dn * 1.000001f; }
         } else if (MODE == GD_MODE_FORCE) {
             p.fout[(size_t)r * p.N + oid] = make_float4(F.x, F.y, F.z, 0.f);
         }
@@ -715,15 +730,32 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
     }
 #endif
     // ---- block reductions: wall reaction partial (deterministic), energy, max displacement
+    // running maximum of the displacement since the build, for the far-class test of the NEXT step: one atomic per block
+    // (folded into the reaction reduction) or per wave, only from those that raise the value this launch started from, each
+    // replica's word on a cache line of its own (right after a build every wave raises it: 60 000 atomics on four lines
+    // took longer than the step itself)
+    const bool track = MODE == GD_MODE_STEP && TILED, record = MODE == GD_MODE_STEP && p.record_disp;
+    const float dwave = track ? wave_max_f(dnew2) : 0.f;
+    // the interval adaptation's measurement (last step of an interval only): exact displacement of the positions read.  It
+    // takes the block reduction's fourth column on that step; the running maximum then goes by wave (late in an interval few
+    // waves still raise it)
+    const float rwave = record ? wave_max_f(disp2) : 0.f;
     if (p.wall.enabled && MODE != GD_MODE_ENERGY) {
         const float sx = wave_sum_f(react.x), sy = wave_sum_f(react.y), sz = wave_sum_f(react.z);
-        if (lane == 0) { s_red[wid][0] = sx; s_red[wid][1] = sy; s_red[wid][2] = sz; }
+        if (lane == 0) { s_red[wid][0] = sx; s_red[wid][1] = sy; s_red[wid][2] = sz; s_red[wid][3] = record ? rwave : dwave; }
         __syncthreads();
         if (tid == 0) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int w = 0; w < GD_BLOCK / 64; w++) { v.x += s_red[w][0]; v.y += s_red[w][1]; v.z += s_red[w][2]; }
+            float m = 0.f;
+            for (int w = 0; w < GD_BLOCK / 64; w++) { v.x += s_red[w][0]; v.y += s_red[w][1]; v.z += s_red[w][2]; m = fmaxf(m, s_red[w][3]); }
             p.react_out[(size_t)r * p.nblk + blk] = v;
+            if (record) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_MAXDISP2], __float_as_uint(m));
+            else if (track && m > dmax0) atomicMax(&p.dmax[r * GD_DMAX_STRIDE], __float_as_uint(m));
         }
+        if (record && track && lane == 0 && dwave > dmax0) atomicMax(&p.dmax[r * GD_DMAX_STRIDE], __float_as_uint(dwave));
+    } else if (lane == 0) {
+        if (track && dwave > dmax0) atomicMax(&p.dmax[r * GD_DMAX_STRIDE], __float_as_uint(dwave));
+        if (record) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_MAXDISP2], __float_as_uint(rwave));
     }
     if (MODE == GD_MODE_ENERGY) {
         const double se = wave_sum_d((double)E);
@@ -734,10 +766,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_step(const StepParams p)
             for (int w = 0; w < GD_BLOCK / 64; w++) v += s_e[w];
             p.epart[(size_t)r * p.nblk + blk] = v;
         }
-    }
-    if (MODE == GD_MODE_STEP && p.record_disp) {
-        const float m = wave_max_f(disp2);
-        if (lane == 0) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_MAXDISP2], __float_as_uint(m));
     }
 }
 
@@ -890,7 +918,7 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
     };
 
     Pre cur, nxt;
-    cur.mo = make_uint2(GD_REC_NONE << 12, 0u); cur.x = make_uint4(0, 0, 0, 0);
+    cur.mo = make_uint2(0u, GD_REC_NOBEAD); cur.x = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < GD_PF; j++) cur.q[j] = make_uint4(0, 0, 0, 0);
     nxt = cur;
@@ -974,8 +1002,8 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
         const size_t rbase = (size_t)r * p.Np;
         const float4 *__restrict__ rpos = p.pos_in + rbase;
         const size_t gt = rbase + blk * GD_BLOCK + t;
-        const unsigned local = (cur.mo.x >> 12) & 0x3ffu, cnt = cur.mo.x >> 22, oid = cur.mo.y;
-        const bool valid = ok && local != GD_REC_NONE;
+        const unsigned local = (cur.mo.x >> 12) & 0x1ffu, nA = (cur.mo.x >> 21) & 31u, nB = (cur.mo.x >> 26) & 31u, oid = cur.mo.y;
+        const bool valid = ok && oid != GD_REC_NOBEAD;
         const size_t g = rbase + blk * GD_BLOCK + (valid ? local : 0u);
         float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (__builtin_amdgcn_readfirstlane((int)tile_ok) != 0) { if (valid) xi4 = tile[own_base + local]; }
@@ -1016,7 +1044,10 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
                 if (!(lim > 0.f) || disp2 > lim * lim) p.flags[r * GD_NFLAGS + GD_FLAG_VIOLATION] = 1u;
             }
             const bool mix = (PK == 1) || (PK == 0 && p.pair.mix != 0);
-            const unsigned nch = (cnt + GD_UNROLL - 1u) / GD_UNROLL;          // chunks in use (padded with the bead itself)
+            // chunks in use: the near class (0 .. nA-1) followed by the far class (NCL-1 downwards); this kernel always
+            // takes both.  The role takes every second chunk of that sequence; the first GD_PF of them are prefetched on the
+            // assumption that they are near chunks (which have the sequence index as their chunk index)
+            const unsigned nch = nA + nB;
             // one 16-byte chunk = 8 entries, evaluated as two groups of four LDS gathers (the register budget of four
             // waves per SIMD: two tiles' worth of prefetched records and chunks stay live across the loop)
             auto half = [&](const unsigned e0, const unsigned e1) {
@@ -1051,13 +1082,12 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
                 }
             };
             auto chunk = [&](const uint4 q) { half(q.x, q.y); half(q.z, q.w); };
-            if (role < nch) chunk(cur.q[0]);
-            if (role + 2u < nch) chunk(cur.q[1]);
-            if (role + 4u < nch) chunk(cur.q[2]);
-            if (role + 2u * GD_PF < nch) {     // lists beyond the prefetched chunks (rare): plain loads
-                const uint4 *ls = (const uint4 *)p.nbr16 + (size_t)(gt >> 6) * NCL * 64 + (gt & 63);
-                for (unsigned c = role + 2u * GD_PF; c < nch; c += 2u) { uint4 q = ls[(size_t)c * 64]; GD_CONSUME4(q); chunk(q); }
-            }
+            const uint4 *ls = (const uint4 *)p.nbr16 + (size_t)(gt >> 6) * NCL * 64 + (gt & 63);
+            auto fetch = [&](unsigned k) { uint4 q = ls[(size_t)(k < nA ? k : NCL - 1u - (k - nA)) * 64]; GD_CONSUME4(q); return q; };   // plain load
+            if (role < nch) chunk(role < nA ? cur.q[0] : fetch(role));
+            if (role + 2u < nch) chunk(role + 2u < nA ? cur.q[1] : fetch(role + 2u));
+            if (role + 4u < nch) chunk(role + 4u < nA ? cur.q[2] : fetch(role + 4u));
+            for (unsigned k = role + 2u * GD_PF; k < nch; k += 2u) chunk(fetch(k));     // beyond the prefetched chunks (rare)
         }
 
         GD_PSTAMP(6);     // pairs
@@ -1289,6 +1319,8 @@ __global__ void k_build_init(const BuildParams p)
     const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.R) return;
     p.lcount[r] = 0ull;
+    p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
+    if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
 }
 
 // per-block bounding box partials (open box): bbox[(r*nblk + blk)*6 + {lo xyz, hi xyz}]
@@ -1475,6 +1507,7 @@ __global__ void k_tiles(const BuildParams p)
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.R * p.nblk) return;
     const unsigned r = t / p.nblk, blk = t % p.nblk;
+    const bool taint = p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] != 0u;      // (positions not trustworthy: report no needs)
     const size_t rbase = (size_t)r * p.Np;
     const GridP gp = p.grid[r];
     const unsigned *__restrict__ cs = p.cell_start + (size_t)r * (p.ncell_cap + 1);
@@ -1501,8 +1534,8 @@ __global__ void k_tiles(const BuildParams p)
         unsigned total = 0; int nm = 0; bool truncated = !ok;
         for (int k = 0; k < GD_TILE_RANGES; k++) { td.start[k] = 0; td.len[k] = 0; td.base[k] = 0; td.kstart[k] = 0xffffffffu; td.kbase[k] = 0; }
         if (!ok) {      // grid too small (aliasing neighbours) or too large for the row bitmap: generic path
-            p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
-            atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], 1u << 20);
+            if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
+            if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], 1u << 20);
         }
         for (int q = 0; ok && q < nrows; ) {
             if (!((bits[q >> 5] >> (q & 31)) & 1u)) { q++; continue; }
@@ -1510,9 +1543,9 @@ __global__ void k_tiles(const BuildParams p)
             while (e + 1 < nrows && ((bits[(e + 1) >> 5] >> ((e + 1) & 31)) & 1u)) e++;
             const unsigned st = cs[q * nx], len = cs[(e + 1) * nx] - st;
             if (nm >= GD_TILE_RANGES || total + len > p.tile_cap) {
-                p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
+                if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
                 // too many ranges cannot be cured by a larger tile: report a need beyond every capacity
-                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], nm >= GD_TILE_RANGES ? 1u << 20 : total + len);
+                if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], nm >= GD_TILE_RANGES ? 1u << 20 : total + len);
                 truncated = true;
                 break;
             }
@@ -1525,7 +1558,7 @@ __global__ void k_tiles(const BuildParams p)
         td.own_base = 0;
         for (int k = 0; k < nm && !truncated; k++)
             if (first - td.start[k] < td.len[k]) td.own_base = td.base[k] + (first - td.start[k]);
-        atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
+        if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
         p.tiles[t] = td;
         return;
     }
@@ -1547,8 +1580,8 @@ __global__ void k_tiles(const BuildParams p)
         unsigned st = 0, len = 0;
         if (k < nm) { st = cs[mlo[k]]; len = cs[mhi[k] + 1] - st; }
         if (total + len > p.tile_cap) {   // does not fit the LDS budget: flag, host rolls back and re-plans
-            p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
-            atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total + len);
+            if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
+            if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total + len);
             len = 0; truncated = true;
         }
         td.start[k] = st; td.len[k] = len; td.base[k] = total;
@@ -1567,7 +1600,7 @@ __global__ void k_tiles(const BuildParams p)
     for (int k = 0; k < nm && !truncated; k++)
         if (first - td.start[k] < td.len[k]) td.own_base = td.base[k] + (first - td.start[k]);
 
-    atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
+    if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
     p.tiles[t] = td;
 }
 
@@ -1642,7 +1675,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     GD_FSTAMP(0);     // staging + barrier
     unsigned cnt = 0;
     if (slot < p.N) {
-        unsigned listlen = 0;
+        unsigned listlen = 0, nA = 0, nB = 0;
         const unsigned o = p.orig_out[g];
         const unsigned *so = p.slot_of + (size_t)r * p.N;
         auto to_local = [&](unsigned ps, unsigned &idx) -> bool {   // slot -> tile index
@@ -1692,6 +1725,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             int cx, cy, cz;
             cell_coords<PERIODIC>(gp, xi, p.inv_box, cx, cy, cz);
             const float rv2 = p.rv * p.rv;
+            // Tiled lists are kept in TWO classes by the distance at the build: "near" entries (closer than rn) in the chunks
+            // from the front of the bead's row, "far" entries (rn <= d < rv) in the chunks from its back.  A pair that is not
+            // in the near class was at least rn apart at the build, so while cutoff + 2 x (largest displacement since the
+            // build) <= rn it exerts no force and k_step leaves the far chunks alone -- most steps of an interval.
+            const float dnear = rv2 - p.rn * p.rn;           // (r2 - rv2) + dnear = r2 - rn2
             // list writer: entries go straight into the wave-interleaved 16-byte chunk layout k_step
             // reads (8 x u16 tiled, 4 x u32 generic); a bead's 8 (4) consecutive entries share one chunk.
             constexpr unsigned PER = TILED ? 8u : 4u;
@@ -1707,6 +1745,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             auto flush = [&]() {
                 if (pend) { lst[(size_t)(pend - 1) * 64] = make_uint4(p0, p1, p2, p3); pend = 0; }      // (non-temporal stores here cost 15%: the partial lines no longer merge in L2)
             };
+            unsigned cntB = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;      // far class (tiled): its own shift register, chunks stored from the back
             auto push = [&](unsigned j) {
                 if (TILED) {        // 128-bit shift register: eight 16-bit entries, the first one ends up lowest
                     w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
@@ -1715,10 +1754,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     w0 = w1; w1 = w2; w2 = w3; w3 = j;
                 }
                 cnt++;
-                if (cnt % PER == 0 && cnt <= p.W) {
+                if (cnt % PER == 0 && cnt + cntB <= p.W) {
                     flush();                                   // (only if a second chunk fills before the next flush point)
                     p0 = w0; p1 = w1; p2 = w2; p3 = w3; pend = cnt / PER;
                 }
+            };
+            auto push_far = [&](unsigned j) {                  // (tiled only; far chunks are few: stored as they fill)
+                b0 = __builtin_amdgcn_alignbit(b1, b0, 16); b1 = __builtin_amdgcn_alignbit(b2, b1, 16);
+                b2 = __builtin_amdgcn_alignbit(b3, b2, 16); b3 = __builtin_amdgcn_alignbit(j, b3, 16);
+                cntB++;
+                if (cntB % 8u == 0 && ((cnt + 7u) & ~7u) + cntB <= p.W) lst[(size_t)(NC - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3);
             };
             if (TILED && PERIODIC) {
                 // periodic tile = whole rows: for each of the 9 wrapped (dz,dy) rows the x-window cx-1..cx+1 is one
@@ -1743,7 +1788,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                         const unsigned self_l = lb + (slot - b);
                         for (unsigned j0 = lb; j0 < le; j0 += 32) {
                             const unsigned n = min(32u, le - j0);
-                            unsigned m = 0;
+                            unsigned m = 0, mn = 0;
                             for (unsigned u0 = 0; u0 < n; u0 += 4) {
                                 const float4 *cj = s_tile + j0 + u0;
 #pragma unroll
@@ -1752,15 +1797,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                                     const float3 d = min_image(make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z), p.box, p.inv_box);
                                     const float t = fmaf(d.z, d.z, fmaf(d.y, d.y, fmaf(d.x, d.x, -rv2)));
                                     m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);
+                                    mn = __builtin_amdgcn_alignbit(mn, __float_as_uint(t + dnear), 31);
                                 }
                             }
-                            m >>= ((n + 3u) & ~3u) - n;
+                            m >>= ((n + 3u) & ~3u) - n; mn >>= ((n + 3u) & ~3u) - n;
                             const unsigned sd = self_l - j0;
                             if (sd < n) m &= ~(1u << (n - 1u - sd));
+                            mn &= m; m ^= mn;                                 // near class, far class
+                            while (mn) {
+                                const unsigned bit = 31u - (unsigned)__clz(mn);
+                                mn ^= 1u << bit;
+                                push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
+                            }
                             while (m) {
                                 const unsigned bit = 31u - (unsigned)__clz(m);
                                 m ^= 1u << bit;
-                                push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
+                                push_far(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
                             }
                         }
                     }
@@ -1793,11 +1845,12 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                         // the (divergent) append code runs max-popcount times per segment, not once per candidate
                         for (unsigned j0 = lb; j0 < le; j0 += 32) {
                             const unsigned n = min(32u, le - j0);
-                            unsigned m = 0;
-                            // seven instructions per candidate: r2 - rv2 by three subtractions and three fmas, and
-                            // its sign bit shifted into the mask by one v_alignbit (candidate i of the n4 tested ends
-                            // up at bit n4-1-i).  Reads may run up to 3 slots past the window (slack is allocated
-                            // behind the tile); those bits are shifted out below, the bead itself is masked once.
+                            unsigned m = 0, mn = 0;
+                            // nine instructions per candidate: r2 - rv2 by three subtractions and three fmas, its sign bit
+                            // shifted into the mask by one v_alignbit (candidate i of the n4 tested ends up at bit
+                            // n4-1-i), one add and one more v_alignbit for the near-class mask.  Reads may run up to 3
+                            // slots past the window (slack is allocated behind the tile); those bits are shifted out
+                            // below, the bead itself is masked once.
                             for (unsigned u0 = 0; u0 < n; u0 += 4) {
 #if GD_ABL == 34
                                 facc_[8] += 1;        // wave-level test groups (lane 0 runs while any lane does)
@@ -1809,19 +1862,26 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                                     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
                                     const float t = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, -rv2)));      // < 0 inside the list radius
                                     m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);              // m = m << 1 | sign(t)
+                                    mn = __builtin_amdgcn_alignbit(mn, __float_as_uint(t + dnear), 31);    // < 0 inside the near radius
                                 }
                             }
-                            m >>= ((n + 3u) & ~3u) - n;                      // candidate i now at bit n-1-i
+                            m >>= ((n + 3u) & ~3u) - n; mn >>= ((n + 3u) & ~3u) - n;          // candidate i now at bit n-1-i
                             const unsigned sd = self_l - j0;
                             if (sd < n) m &= ~(1u << (n - 1u - sd));
+                            mn &= m; m ^= mn;                                // near class, far class
                             GD_FSTAMP(3);     // distance tests
-                            while (m) {                                      // ascending candidate order
+                            while (mn) {                                     // ascending candidate order
 #if GD_ABL == 34
                                 facc_[9] += 1;
 #endif
+                                const unsigned bit = 31u - (unsigned)__clz(mn);
+                                mn ^= 1u << bit;
+                                push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
+                            }
+                            while (m) {
                                 const unsigned bit = 31u - (unsigned)__clz(m);
                                 m ^= 1u << bit;
-                                push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
+                                push_far(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
                             }
                             GD_FSTAMP(4);     // appends
                         }
@@ -1855,30 +1915,34 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     }
                 }
             }
-            const unsigned found = cnt;
-            if (found > p.W) {
-                p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
-                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], found);
-            }
-            listlen = min(found, p.W);
-            // pad to a multiple of GD_UNROLL (W is one) with the bead itself: zero displacement, zero force
+            const unsigned found = cnt + cntB;
+            // pad both classes to whole chunks with the bead itself: zero displacement, zero force
             unsigned self = slot;
             if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = S16 ? idx << 4 : idx; }
+            const unsigned needw = ((cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u)) + ((cntB + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u));
+            if ((needw > p.W || (TILED && needw > GD_TILED_MAX_W)) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
+                p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
+                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], needw);
+            }
+            listlen = min(found, p.W);
             while (cnt % GD_UNROLL) push(self);
             flush();
+            if (TILED) while (cntB % GD_UNROLL) push_far(self);
+            // (an overflowed list is flagged and its chunk rolled back; the chunk counts still have to stay inside the row)
+            nA = min(min(cnt / GD_UNROLL, 31u), NC); nB = min(min(cntB / GD_UNROLL, 31u), NC - nA);
             cnt = found;
         }
         const unsigned meta = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
         if (TILED) {
             const float4 xb = rpos[slot];
             p.rec_x0[gt] = make_float4(xb.x, xb.y, xb.z, __uint_as_float(slot - blk * GD_BLOCK));
-            // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | list length << 22 (GD_REC_*; the
-            // host keeps the list width of tiled lists <= 1016), bead id
-            p.rec_mo[gt] = make_uint2(deg | (((unsigned)p.psmask_o[o] & 0xfu) << 8) | ((slot - blk * GD_BLOCK) << 12) | (listlen << 22), o);
-            p.len_prev[(size_t)r * p.N + o] = (unsigned char)min((listlen + GD_UNROLL - 1u) / GD_UNROLL, 30u);
+            // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | near chunks << 21 | far chunks << 26
+            // (at most 31 chunks per class: the host keeps the width of tiled lists <= GD_TILED_MAX_W), bead id (~0: no bead)
+            p.rec_mo[gt] = make_uint2(deg | (((unsigned)p.psmask_o[o] & 0xfu) << 8) | ((slot - blk * GD_BLOCK) << 12) | (nA << 21) | (nB << 26), o);
+            p.len_prev[(size_t)r * p.N + o] = (unsigned char)min(nA, 30u);       // (the near class is what most steps run over)
         } else p.meta[g] = meta;
     }
-    if (TILED && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(GD_REC_NONE << 12, 0u); }
+    if (TILED && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
     GD_FSTAMP(5);     // padding, meta
     unsigned long long c64 = min(cnt, p.W);
     unsigned cmax = cnt;
@@ -1890,7 +1954,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         unsigned m = 0;
         for (int w = 0; w < GD_BLOCK / 64; w++) { t += s_cnt[w]; m = max(m, s_max[w]); }
         if (t) atomicAdd(&p.lcount[r], t);
-        if (m) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
+        if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
     }
     GD_FSTAMP(6);     // count
 #if GD_ABL == 34
@@ -2021,12 +2085,13 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
         if (tid < sizeof(TileDesc) / 4) ((unsigned *)&s_td)[tid] = src[tid];
         __syncthreads();
     }
-    unsigned slot = blk * GD_BLOCK + tid, cnt = 0;
+    unsigned slot = blk * GD_BLOCK + tid, cnt = 0, nA = 0;      // tiled: cnt = entries of both classes, padding included
     bool valid = slot < p.N;
     if (TILED) {
         const uint2 mo = p.rec_mo[gt];
-        const unsigned local = (mo.x >> 12) & 0x3ffu;
-        valid = local != GD_REC_NONE; slot = blk * GD_BLOCK + (valid ? local : 0u); cnt = mo.x >> 22;
+        const unsigned local = (mo.x >> 12) & 0x1ffu;
+        nA = (mo.x >> 21) & 31u;
+        valid = mo.y != GD_REC_NOBEAD; slot = blk * GD_BLOCK + (valid ? local : 0u); cnt = (nA + ((mo.x >> 26) & 31u)) * 8u;
     } else if (valid) cnt = p.meta[rbase + slot] >> 16;
     const float4 *__restrict__ rpos = p.pos + rbase;
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2040,8 +2105,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
     const size_t gl = TILED ? gt : rbase + slot;
     const unsigned PER = TILED ? 8u : 4u, NC = p.W / PER;
     const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(gl >> 6) * NC * 64 + (gl & 63);
-    auto partner = [&](unsigned k) -> unsigned {       // slot of list entry k
-        const uint4 q = lst[(size_t)(k / PER) * 64];
+    auto partner = [&](unsigned k) -> unsigned {       // slot of list entry k (tiled: near chunks from the front, far chunks from the back)
+        const unsigned c = k / PER;
+        const uint4 q = lst[(size_t)(TILED && c >= nA ? NC - 1u - (c - nA) : c) * 64];
         const unsigned w = k % PER;
         if (!TILED) return w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
         const unsigned word = (w >> 1) == 0 ? q.x : (w >> 1) == 1 ? q.y : (w >> 1) == 2 ? q.z : q.w;

@@ -25,15 +25,18 @@
 #define GD_CHAIN_LOCAL 0x40000000          // same for chain (bending) partners
 #define GD_TILE_RANGES 9                   // (dz,dy) rows of the 27-cell neighbourhood
 #define GD_XCDS 8
-#define GD_REC_NONE 0x3ffu                 // tiled per-thread record: block-local slot field of a thread without a bead
-#define GD_TILED_MAX_W 1016u                // list length field of the tiled record: 10 bits
+#define GD_REC_NOBEAD 0xffffffffu          // tiled per-thread record: bead id of a thread without a bead
+#define GD_TILED_MAX_W 496u                 // tiled record: 5-bit chunk counts for the near and the far class (2 x 31 x 8 entries)
+#define GD_DMAX_STRIDE 32u                  // words between the replicas' displacement maxima: one 128-byte line each
 #define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 
 enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
 
 // flags[r*GD_NFLAGS + k]
 enum { GD_FLAG_VIOLATION = 0, GD_FLAG_OVERFLOW = 1, GD_FLAG_MAXDISP2 = 2, GD_FLAG_NEED_W = 3, GD_FLAG_TILE_OVERFLOW = 4,
-       GD_FLAG_NEED_TILE = 5, GD_NFLAGS = 8 };
+       GD_FLAG_NEED_TILE = 5, GD_FLAG_TAINT = 6, GD_NFLAGS = 8 };
+// GD_FLAG_TAINT: set by a list build that starts after an overflow was flagged in the same chunk -- the steps since ran on
+// incomplete lists, the positions are no basis for sizing anything: such a build reports no needs (the chunk is rolled back)
 
 // LDS tile of one block (tiled path): the block's 256 slots plus the slots of every cell adjacent
 // to its cells, as 9 contiguous slot ranges (one per (dz,dy) row offset of the cell grid).
@@ -177,6 +180,8 @@ struct StepParams {
     int noise_mode, run_flags;
     const float *host_noise;            // (R, N, 3) normals of this step
     float rv;                           // list radius (violation check)
+    float rn;                           // near-class radius of the tiled list in use
+    unsigned *dmax;                     // [R] largest squared displacement since the build, float bits (monotone between builds)
     int record_disp;
     // force / energy modes
     unsigned term_mask;
@@ -190,6 +195,8 @@ struct BuildParams {
     int periodic;
     float box[3], inv_box[3];
     float rv;
+    float rn;                           // near-class radius of tiled lists (cutoff < rn <= rv)
+    unsigned *dmax;                     // [R] largest squared displacement since the build (float bits)
     unsigned ncell_cap;
     const float4 *pos_in;               // current order
     float4 *pos_out;                    // new (sorted) order

@@ -16,7 +16,7 @@ else:
     s.begin_phase(); s.run(EQ, 1e-5, 1.0, seed=99, flags=0); np.save(snap, s.positions())
 s.begin_phase()
 if not os.environ.get("GDYN_NO_RUN"):      # ablation builds: no stepping with the ablated kernels, time them on the relaxed snapshot
-    s.run(8, 1e-5, 1.0, seed=3, flags=3)
+    s.run(int(os.environ.get("GDYN_RUN_STEPS", "8")), 1e-5, 1.0, seed=3, flags=3)
 c = s.context()
 print(f"lib {os.environ.get('GDYN_LIB','libgdyn.so')}: build {s.debug_bench(0, 20)*1e3:.1f} us  step {s.debug_bench(1, 40)*1e3:.1f} us   L/bead {c.list_entries/30000:.1f} K {c.rebuild_interval}")
 if os.environ.get("GDYN_STAMPS"):
