@@ -100,3 +100,22 @@ def test_replica_farm_gloo_world2(tmp_path, oracle):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "FARM_OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_bench_farm_rehearsal_two_ranks_one_gpu(hip):
+    """The N > 1 path of bench.py exactly as the driver launches it (one process per rank through torch.distributed.run),
+    rehearsed on one MI355X: two ranks share GPU 0, gloo stands in for RCCL (the farm only broadcasts the inputs and
+    gathers summary statistics; there is no collective in the timed region).  Small workload, same code path."""
+    import json
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--dist-backend", "gloo", "--single-device", "--beads", "3000", "--replicas", "8",
+                          "--equil", "200", "--steps", "40", "--warmup", "10", "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_replicas"] == 16
+    assert line["value"] > 0 and line["steps"] == 40 and line["warmup"] == 10
+    assert len(line["config"]["mean_energy_per_bead"]) == 2          # one summary row gathered from each rank
+    assert line["config"]["mean_energy_per_bead"][0] != line["config"]["mean_energy_per_bead"][1]      # independent trajectories

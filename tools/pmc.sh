@@ -12,13 +12,13 @@ for set in "SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TA_BUSY_avr"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/${PMC_SCRIPT:-bench.py} "$@" > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; }
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$tag/p$i -- python3 $GRAFT_REPO_ROOT/${PMC_SCRIPT:-bench.py} "$@" > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("/tmp/pmc_" + out.rsplit("pmc_", 1)[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
         a = agg[k][row["Counter_Name"]]

@@ -1,0 +1,20 @@
+#!/bin/bash
+# tools/profile_round.sh <tag>: the round's evidence in one GPU call -- relaxed state, rocprofv3 kernel stats, PMC passes
+# (separate, no tracing domains), plain bench lines.  Everything lands in gpurun_out/<tag>_*; copy what is judged to profiles/.
+tag=${1:-r02}
+root=$GRAFT_REPO_ROOT; out=$root/gpurun_out
+cd /tmp; export TMPDIR=/tmp
+python3 $root/bench.py --save-state /tmp/state.npy > /dev/null 2>&1
+echo "[profile] state saved"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $root/bench.py --load-state /tmp/state.npy --warmup 300 --steps 1000 --no-cpu-baseline --no-extra > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_bench_under_rocprof.err
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
+python3 $root/tools/kstats.py /tmp/prof_stats > $out/${tag}_bench_kernel_stats.txt
+echo "[profile] kernel stats done"
+PMC_SCRIPT=bench.py bash $root/tools/pmc.sh $tag --load-state /tmp/state.npy --warmup 200 --steps 200 --no-cpu-baseline --no-extra
+cp $out/pmc_$tag/summary.txt $out/${tag}_bench_pmc_summary.txt
+echo "[profile] pmc done"
+cd $root
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+echo "[profile] driver-line bench done"
+python3 bench.py --no-cpu-baseline --no-extra > $out/${tag}_bench_2000steps.json 2> $out/${tag}_bench_2000steps.err
+tail -c 300 $out/${tag}_bench_2000steps.json
