@@ -71,7 +71,13 @@ def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
     farm = None
     fast = os.path.join(ROOT, "oracle", "liboracle_fast.so")
     try:
-        cores = min(len(os.sched_getaffinity(0)), 64)      # the GPU box grants 16 per GPU; stated in the result
+        cores = min(len(os.sched_getaffinity(0)), 64)
+        try:        # a cgroup CPU quota below the affinity mask (the GPU box grants 16 CPUs per GPU): more processes only time-share
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                cores = max(1, min(cores, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
         if os.path.exists(fast) and cores > 1:
             fsteps, fel = _oracle_rate(g, wl, fast, x0, n_beads, 2.0)
             fsteps = int(max(10, budget_s * 0.6 * fsteps / fel))      # the loaded machine runs slower than the 1-core probe
