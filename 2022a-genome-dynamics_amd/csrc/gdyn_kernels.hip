@@ -3,17 +3,23 @@
 //   k_step<MODE,PERIODIC,TILED,PK,S16>
 //                          one thread per bead: neighbour-list pair forces (AB-mixed soft cores), bonded / bending /
 //                          point-source / ellipsoid- and inner-sphere-wall forces, Euler-Maruyama update with
-//                          Philox4x32-10 noise, Verlet-skin check, per-block wall-reaction partials.  TILED: the block's
-//                          beads and their neighbour cells are staged into LDS by DMA and list entries address that
-//                          tile.  The per-step "callback" state (time, bead/bond scale, wall semiaxes ODE; reference
-//                          5-sim-genome/src/simulation_interphase/simulation_driver_interphase.cc:12-80) is advanced
-//                          by wave 0 of every block in the prologue of the NEXT launch: no host round trip per step.
+//                          Philox4x32-10 noise, Verlet-skin check, per-block wall-reaction partials, running displacement
+//                          maximum.  TILED: the block's beads and their neighbour cells are staged into LDS by DMA, list
+//                          entries address that tile, lists come in a near and a far class (the far class is skipped
+//                          while it cannot matter).  The per-step "callback" state (time, bead/bond scale, wall semiaxes
+//                          ODE; reference 5-sim-genome/src/simulation_interphase/simulation_driver_interphase.cc:12-80) is
+//                          advanced by wave 0 of every block in the prologue of the NEXT launch: no host round trip per step.
+//   k_ctx                  one wave per replica: the pending callback at the end of a chunk, the reaction fold of a force
+//                          evaluation, the per-step context of k_step_p.
+//   k_step_p               (opt-in) persistent, double-buffered form of the tiled step kernel: one workgroup per CU walks
+//                          over tiles, two waves per bead; measured slower than k_step.
 //   k_softwell             droplet attraction among the few hundred target beads (after k_step; linear in the force).
 //   k_bbox .. k_fill       neighbour search (micromd md::neighbor_searcher; call sites e.g.
 //                          simulation_interphase/contact_map.cc:64-66): bounding box, cell binning, counting sort into
 //                          slot order, tile descriptors, list fill (27-cell sweep from the LDS tile, or from global
 //                          memory on the generic path).
-//   GD_ABL                 timing-only builds (tools/abl.sh): term ablations 11-15, section stamps 30 / 34.
+//   k_pairs                pair search (contact map, glue candidates) filtered from the resident list.
+//   GD_ABL                 timing-only builds (tools/abl.sh): term ablations 11-15, section stamps 30 / 34 / 40.
 //
 // MFMA is not used: the path is an irregular short-range N-body sum.
 #include <hip/hip_fp16.h>

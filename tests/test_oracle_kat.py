@@ -320,3 +320,30 @@ def test_error_behaviour(oracle):
         s.set_positions(np.full((1, s.N, 3), np.nan))
     with pytest.raises(g.GdynError):
         g.System(oracle, 0, 1)
+
+
+def test_replica_seeds_reproduce_solo_runs(oracle):
+    """gd_run_desc.replica_seeds: replica r of a batched handle draws the stream a ONE-replica run with seed
+    replica_seeds[r] draws (the reference's ensemble is one process per seed, 5-sim-genome/scripts/run_simulation:8-25),
+    so a batched trajectory equals the solo one; without it replica r draws from (seed, r)."""
+    from util import build
+    seeds = np.array([11, 2 ** 40 + 5, 12345], dtype=np.uint64)
+    sb, dt, kT, flags = build(oracle, "genome", n_replicas=3)
+    x0 = sb.positions()
+    x0[1] += 0.01
+    sb.set_positions(x0)
+    sb.begin_phase()
+    sb.run(6, dt, kT, seed=999, flags=flags, replica_seeds=seeds)
+    xb = sb.positions()
+    for r in range(3):
+        s1, *_ = build(oracle, "genome")
+        s1.set_positions(x0[r][None])
+        s1.begin_phase()
+        s1.run(6, dt, kT, seed=int(seeds[r]), flags=flags)
+        assert np.array_equal(s1.positions()[0], xb[r]), r
+        assert s1.context().semiaxes[0] == sb.context(r).semiaxes[0]
+    sc, *_ = build(oracle, "genome", n_replicas=3)
+    sc.set_positions(x0)
+    sc.begin_phase()
+    sc.run(6, dt, kT, seed=int(seeds[0]), flags=flags)
+    assert np.array_equal(sc.positions()[0], xb[0]) and not np.array_equal(sc.positions()[2], xb[2])

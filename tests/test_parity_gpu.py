@@ -99,6 +99,24 @@ def test_replica_batch_matches_oracle(hip, oracle, name, nrep):
         assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), atol=1e-8)
 
 
+@pytest.mark.parametrize("path", ["generic", "tiled"])
+def test_replica_seeds_match_oracle(hip, oracle, path):
+    """gd_run_desc.replica_seeds on the device: replica r draws the stream (replica_seeds[r], 0), as the oracle does (which the
+    CPU suite checks against one-replica runs bit for bit)."""
+    _, _, dt, kT, flags = CASES["genome"]
+    seeds = np.array([11, 2 ** 40 + 5, 12345], dtype=np.uint64)
+    out = []
+    for lib in (hip, oracle):
+        s, *_ = build(lib, "genome", n_replicas=3)
+        if lib is hip:
+            s.set_tuning(kernel_path=PATHS[path])
+        s.begin_phase()
+        s.run(6, dt, kT, seed=999, flags=flags, replica_seeds=seeds)
+        out.append(s.positions())
+    assert np.abs(out[0] - out[1]).max() <= POS_ATOL_20STEP
+    assert np.abs(out[1][0] - out[1][1]).max() > 1e-4
+
+
 @pytest.mark.parametrize("box", [None, (2.9,) * 3, (0.9, 1.3, 2.9)])
 def test_neighbor_search_pair_set(hip, oracle, box):
     """md::neighbor_searcher::search: the pair SET is exact (beads on cell/box boundaries, aliasing small grids)."""
