@@ -1320,15 +1320,6 @@ void gd_launch_step_p(const StepParams &p, unsigned n_cu, hipStream_t st)
 
 // --------------------------------------------------------- neighbour search
 
-__global__ void k_build_init(const BuildParams p)
-{
-    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.R) return;
-    p.lcount[r] = 0ull;
-    p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
-    if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
-}
-
 // per-block bounding box partials (open box): bbox[(r*nblk + blk)*6 + {lo xyz, hi xyz}]
 __global__ __launch_bounds__(GD_BLOCK) void k_bbox(const BuildParams p)
 {
@@ -1387,7 +1378,17 @@ __global__ __launch_bounds__(64) void k_gridp(const BuildParams p)
         if ((float)n0 * (float)n1 * (float)n2 <= (float)p.ncell_cap) break;
         cs *= 1.26f;
     }
+    // the cell counters of this replica's grid start from zero (one wave clears them; replaces a memset of the whole
+    // allocation), and so do the per-build replica counters
+    {
+        unsigned *cc = p.cell_cnt + (size_t)r * (p.ncell_cap + 1);
+        const unsigned ncell = (unsigned)(n0 * n1 * n2);
+        for (unsigned c = lane; c <= ncell && c <= p.ncell_cap; c += 64) cc[c] = 0u;
+    }
     if (lane == 0) {
+        p.lcount[r] = 0ull;
+        p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
+        if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
         GridP *g = p.grid + r;
         g->org[0] = lo0; g->org[1] = lo1; g->org[2] = lo2;
         if (p.periodic) { g->inv[0] = (float)n0 / e0; g->inv[1] = (float)n1 / e1; g->inv[2] = (float)n2 / e2; }
@@ -1496,7 +1497,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
     if (p.packed_ab) x.w = pack_ab(ab);
     const size_t gn = rbase + ns;
     p.pos_out[gn] = x;
-    p.xb[gn] = x;
+    if (!p.tiled) p.xb[gn] = x;      // build positions by slot: the generic path's skin check (the tiled path keeps them per thread, rec_x0)
     p.orig_out[gn] = o;
     p.cell_s[gn] = c;
     p.slot_of[(size_t)r * p.N + o] = ns;
@@ -1977,10 +1978,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 void gd_launch_build(const BuildParams &p, hipStream_t st)
 {
     const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk);
-    hipLaunchKernelGGL(k_build_init, dim3((p.R + 63) / 64), dim3(64), 0, st, p);
     if (!p.periodic) hipLaunchKernelGGL(k_bbox, grid, block, 0, st, p);
     hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(64), 0, st, p);
-    (void)hipMemsetAsync(p.cell_cnt, 0, (size_t)p.R * (p.ncell_cap + 1) * sizeof(unsigned), st);
     if (p.periodic) hipLaunchKernelGGL(k_bin<true>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(k_bin<false>, grid, block, 0, st, p);
     hipLaunchKernelGGL(k_scan, dim3(p.R), dim3(1024), 0, st, p);
