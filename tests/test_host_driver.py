@@ -322,6 +322,24 @@ def test_batched_driver_on_gpu(tmp_path, hip, oracle):
             assert np.allclose(fs[key][1]["wall_semiaxes"], fb[key][1]["wall_semiaxes"], rtol=0, atol=1e-7)
 
 
+@pytest.mark.gpu
+def test_farm_runs_batched_drivers_on_gpu(tmp_path, hip):
+    """gd_farm --gpus 1 gd_interphase f0 f1 f2: the launcher starts one driver process for GPU 0 with all three files (three
+    replicas of one handle); every file gets its relaxation and interphase frames.  (With G GPUs the same command line starts
+    G processes, `--device g` each; this box has one.)"""
+    subprocess.check_call(["make", "-s", "-C", HOST, "gd_farm"])
+    drv = _make("gd_interphase", ".", "../csrc", "gdyn")
+    dirs = _batch_case(tmp_path)
+    r = subprocess.run([os.path.join(HOST, "gd_farm"), "--gpus", "1", str(drv), *[str(d / "traj.h5") for d in dirs]],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "[farm] gpu 0:" in r.stderr and "--device 0" in r.stderr
+    frames = [_frames(d) for d in dirs]
+    for f in frames:
+        assert len(f) == 7 and ("interphase", 60) in f
+    assert not np.array_equal(frames[0][("interphase", 60)][0], frames[1][("interphase", 60)][0])
+
+
 # ---------------------------------------------------------------------------------------------- gd_spindle
 
 SP_COARSE, SP_STEPS, SP_PACK = 2, 40, 30
