@@ -271,16 +271,20 @@ int gd_compute_energy(gd_system *sys, uint32_t term_mask, double *energy /* (R) 
 int gd_compute_forces(gd_system *sys, uint32_t term_mask, double *forces);
 
 /* md::neighbor_searcher<Box>{box,dcut}.set_points().search(out)
- * (simulation_interphase/contact_map.cc:64-66): unique pairs i<j within dcut of
- * replica `replica`; writes up to cap pairs, returns the total in *n_pairs. */
+ * (simulation_interphase/contact_map.cc:64-66, 3-sim-1kb/src/simulation/glues/glue_simulator.cpp:41,67-77): unique pairs
+ * i<j within dcut of replica `replica`, in no particular order; writes up to cap pairs, returns the total in *n_pairs.
+ * Served on the device from the Verlet list that is resident (no rebuild while it covers dcut; otherwise one build at
+ * max(force-list radius, dcut), which leaves a valid force list behind).  Calling it twice without an intervening change of
+ * the positions (count, then fetch) costs one search. */
 int gd_search_pairs(gd_system *sys, uint32_t replica, double dcut,
                     uint32_t *pairs, uint64_t cap, uint64_t *n_pairs);
 
 /* --------------------------------------------------------- tuning / timing */
 
 typedef struct {
-    double   skin;              /* Verlet skin as a fraction of the cutoff: list radius = cutoff * (1 + skin); 0 keeps the
-                                   current value (default 0.75) */
+    double   skin;              /* Verlet skin as a fraction of the NOMINAL pair cutoff: list radius = cutoff * (bead_scale + skin),
+                                   i.e. an absolute width that a scaled-down cutoff does not shrink; 0 keeps the current
+                                   value (default 0.75) */
     uint32_t rebuild_interval;  /* initial steps between list builds; 0 = auto */
     uint32_t adapt_interval;    /* 1 = adapt interval from measured displacements */
     uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
@@ -296,7 +300,8 @@ typedef struct {
     double   rebuild_ms;        /* HIP-event time of the list builds in the last gd_run  */
     double   total_ms;          /* HIP-event time of the whole enqueued region           */
     uint64_t step_launches, rebuild_launches;
-    uint64_t list_entries_visited;  /* sum over step launches of L (all replicas) */
+    uint64_t list_entries_visited;  /* sum over step launches of L, the directed entries stored (all replicas; tiled lists skip
+                                       the far class in most steps, so fewer are evaluated) */
 } gd_timing;
 
 int gd_get_timing(gd_system *sys, gd_timing *out);
