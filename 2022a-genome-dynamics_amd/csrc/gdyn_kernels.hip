@@ -346,13 +346,14 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
             // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
             // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
             // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
+            const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)(wid * 64u));
             if (wid == 0 && lane < 2 * GD_MAX_BOND_TYPES)       // the bond-type table: 32 B per type, 16 B per lane (the buffer always holds the full table)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)p.btab + lane),
                                                  (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
 #pragma unroll
             for (int k = 0; k < GD_TILE_RANGES; k++) {
                 const unsigned len = tlen[k], st = tst[k], base = tbase[k];
-                for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
+                for (unsigned q0 = wq; q0 < len; q0 += GD_BLOCK) {      // (wave-uniform loop: scalar control, one compare per lane)
                     if (q0 + lane < len)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
                                                          (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
@@ -1663,12 +1664,13 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     if (TILED && GD_ABL != 4) {
         // LDS-DMA staging as in k_step: descriptor by scalar loads first, then all pieces back to back
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
+        const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)(wid * 64u));
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = tdp->len[k]; tst[k] = tdp->start[k]; tbase[k] = tdp->base[k]; }
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
             const unsigned len = tlen[k], st = tst[k], base = tbase[k];
-            for (unsigned q0 = wid * 64; q0 < len; q0 += GD_BLOCK) {
+            for (unsigned q0 = wq; q0 < len; q0 += GD_BLOCK) {
                 if (q0 + lane < len)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
                                                      (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
