@@ -325,6 +325,8 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
     // The bead's own position is read from the tile after the barrier (tile index own_base + block-local slot), so no
     // load depends on another one.
     const size_t gt = rbase + blk * GD_BLOCK + tid;      // tiled path: the thread's record position (balanced thread order)
+    // (its wave index is wave-uniform: chunk addresses are a scalar base + lane, no per-lane 64-bit multiplies)
+    const size_t gw6 = (rbase + blk * GD_BLOCK) / 64 + (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)wid);
     const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
     uint2 mo = make_uint2(0u, 0u);
     float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -364,8 +366,8 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
         // three more loads per thread, unconditionally (every array is allocated for all threads of the block); nothing
         // before the barrier waits for them
         rec = p.rec_x0[gt];
-        adj0 = ((const uint4 *)p.badj)[(size_t)(gt >> 6) * NCB * 64 + (gt & 63)];
-        qa = nt_load((const uint4 *)p.nbr16 + (size_t)(gt >> 6) * NCL * 64 + (gt & 63));
+        adj0 = ((const uint4 *)p.badj)[gw6 * NCB * 64 + lane];
+        qa = nt_load((const uint4 *)p.nbr16 + gw6 * NCL * 64 + lane);
         GD_STAMP(8);      // per-bead loads issued
     } else {
         for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
@@ -374,8 +376,8 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
     unsigned slot = blk * GD_BLOCK + tid;
     bool valid = slot < p.N;
     size_t g = rbase + slot;
-    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)((TILED ? gt : g) >> 6) * NCL * 64 + ((TILED ? gt : g) & 63);
-    const uint4 *__restrict__ adj = (const uint4 *)p.badj + (size_t)((TILED ? gt : g) >> 6) * NCB * 64 + ((TILED ? gt : g) & 63);
+    const uint4 *__restrict__ lst = TILED ? (const uint4 *)p.nbr16 + gw6 * NCL * 64 + lane : (const uint4 *)p.nbr + (size_t)(g >> 6) * NCL * 64 + (g & 63);
+    const uint4 *__restrict__ adj = (const uint4 *)p.badj + (TILED ? gw6 * NCB * 64 + lane : (size_t)(g >> 6) * NCB * 64 + (g & 63));
     float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f), x0 = xi4;
     unsigned meta = 0, oid = 0;
     float mu = p.mob_uniform;
