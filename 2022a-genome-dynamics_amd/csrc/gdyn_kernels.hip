@@ -255,6 +255,13 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
     o.semi[0] = (float)c.semi[0]; o.semi[1] = (float)c.semi[1]; o.semi[2] = (float)c.semi[2];
     o.inv_bond_scale2 = (float)(1.0 / (c.bond_scale * c.bond_scale));
     o.near2 = 0.f; o.w_inv_sa2 = 0.f; o.w_inv_sb2 = 0.f; o.w_ca = 0.f; o.w_cb = 0.f;
+    {   // block-uniform constants of the pair term and of the integrator: divisions and the square root once per block
+        const float sc = p.pair.scaled ? (float)c.bead_scale : 1.0f;
+        const float sa = p.pair.sigma_a * sc, sb = p.pair.sigma_b * sc;
+        o.p_inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f; o.p_inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
+        o.p_cut = p.pair.cutoff * sc;
+        o.sg_uniform = p.mob_uniform >= 0.f ? sqrtf(2.0f * p.kT * p.mob_uniform * p.dt) : -1.0f;
+    }
     for (int k = 0; k < 3; k++) { o.inv_semi[k] = 0.f; o.inv_semi2[k] = 0.f; }
     if (p.wall.enabled) {
         float smin = 3.4e38f;
@@ -453,10 +460,8 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
 
         // ---- non-bonded pairs over the Verlet list (a3, a5)
         if (GD_ABL != 11 && p.pair.enabled && (mask & TERM_PAIR)) {
-            const float sc = p.pair.scaled ? s_ctx.bead_scale : 1.0f;
-            const float sa = p.pair.sigma_a * sc, sb = p.pair.sigma_b * sc;
-            const float inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f, inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
-            const float cut = p.pair.cutoff * sc, cut2 = cut * cut;
+            const float inv_sa2 = s_ctx.p_inv_sa2, inv_sb2 = s_ctx.p_inv_sb2;      // (block-uniform: computed once, fill_ctxf)
+            const float cut = s_ctx.p_cut, cut2 = cut * cut;
             const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb = 24.0f * p.pair.eps_b * inv_sb2;
             const float hca = 0.5f * ca, hcb = 0.5f * cb, Ai = hca * abi.x, Bi = hcb * abi.y;
             if (MODE == GD_MODE_STEP) {
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
             GD_STAMP(5);  // wall
             // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
             const float mu_dt = mu * p.dt;
-            const float sg = sqrtf(2.0f * p.kT * mu_dt);
+            const float sg = s_ctx.sg_uniform >= 0.f ? s_ctx.sg_uniform : sqrtf(2.0f * p.kT * mu_dt);
             const float ex = mu_dt * F.x + sg * z.x, ey = mu_dt * F.y + sg * z.y, ez = mu_dt * F.z + sg * z.z;
             p.pos_out[g] = make_float4(xi.x + ex, xi.y + ey, xi.z + ez, xi4.w);
             // displacement of the NEW position since the build, bounded by the triangle inequality (the build position
@@ -864,7 +869,7 @@ void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st)
 // lgkmcnt(0) so that they do not drain the DMAs in flight.
 #define GD_PBLOCK 1024
 #define GD_PF 3                                     // list chunks a role-thread prefetches per tile (2 x 3 x 8 = 48 entries per bead)
-#define GD_P_EXTRA (2 * GD_BLOCK + 32 + 10 + 24 + 16) // float4 beyond the two tiles: 2 x role-B forces, bond table, 2 contexts, 3 descriptors, 2 x reductions
+#define GD_P_EXTRA (2 * GD_BLOCK + 32 + 12 + 24 + 16) // float4 beyond the two tiles: 2 x role-B forces, bond table, 2 contexts, 3 descriptors, 2 x reductions
 
 template <bool PERIODIC, int PK, unsigned role>
 __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s_all)
@@ -872,10 +877,10 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
     const unsigned cap = p.tile_cap;
     float4 *const s_F = s_all + 2 * cap;                                  // [2][GD_BLOCK] partial forces of role B
     const BondType *const s_bt = (const BondType *)(s_F + 2 * GD_BLOCK);
-    CtxF *const s_ctxf = (CtxF *)(s_F + 2 * GD_BLOCK + 32);               // [2]
-    unsigned *const s_desc = (unsigned *)(s_F + 2 * GD_BLOCK + 42);       // [3][32]: a ring -- the descriptor of tile it+1 is written
+    CtxF *const s_ctxf = (CtxF *)(s_F + 2 * GD_BLOCK + 32);               // [2] x 96 B = 12 float4
+    unsigned *const s_desc = (unsigned *)(s_F + 2 * GD_BLOCK + 44);       // [3][32]: a ring -- the descriptor of tile it+1 is written
                                                                           // while slow waves may still be reading that of tile it-1
-    float *const s_red = (float *)(s_F + 2 * GD_BLOCK + 66);              // [2][8][4]
+    float *const s_red = (float *)(s_F + 2 * GD_BLOCK + 68);              // [2][8][4]
 
     const unsigned tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = tid & (GD_BLOCK - 1);
     const unsigned ntile = p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk;
@@ -936,7 +941,7 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
     bool has_next = bn < ntile, okn = has_next && block_map(bn, p.nblk, p.cpb, rn, blkn);
     unsigned dreg = 0, creg = 0;
     if (wid == 0 && lane < 32 && okn) dreg = ((const unsigned *)(p.tiles + (size_t)rn * p.nblk + blkn))[lane];
-    if (wid == 1 && lane < 20 && ok) creg = ((const unsigned *)(p.ctxf + r))[lane];
+    if (wid == 1 && lane < GD_CTXF_DWORDS && ok) creg = ((const unsigned *)(p.ctxf + r))[lane];
 
     const float sg_dt = p.dt;
 #if GD_ABL == 40      // timing-only build: shader-clock stamps per loop section, summed per wave (tools/ubench.py GDYN_PSTAMPS=1)
@@ -985,7 +990,7 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
         GD_PSTAMP(1);     // wait for the tile's loads and DMAs
         const unsigned ds = it % 3u, dsn = (it + 1u) % 3u;      // descriptor slots of this tile and the next
         if (wid == 0 && lane < 32) s_desc[dsn * 32 + lane] = dreg;
-        if (wid == 1 && lane < 20) ((unsigned *)(s_ctxf + cb))[lane] = creg;
+        if (wid == 1 && lane < GD_CTXF_DWORDS) ((unsigned *)(s_ctxf + cb))[lane] = creg;
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) alone
         __builtin_amdgcn_s_barrier();
         GD_PSTAMP(2);     // barrier
@@ -999,7 +1004,7 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
             bnn = bn + gridDim.x; has_nn = bnn < ntile; oknn = has_nn && block_map(bnn, p.nblk, p.cpb, rnn, blknn);
             dreg = 0; creg = 0;
             if (wid == 0 && lane < 32 && oknn) dreg = ((const unsigned *)(p.tiles + (size_t)rnn * p.nblk + blknn))[lane];
-            if (wid == 1 && lane < 20 && okn) creg = ((const unsigned *)(p.ctxf + rn))[lane];
+            if (wid == 1 && lane < GD_CTXF_DWORDS && okn) creg = ((const unsigned *)(p.ctxf + rn))[lane];
         }
 
         GD_PSTAMP(4);     // prefetch issue
@@ -1037,10 +1042,8 @@ __device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s
         // ---- non-bonded pairs: this role's chunks of the Verlet list (a3, a5)
         float disp2 = 0.f;
         if (valid && p.pair.enabled) {
-            const float sc = p.pair.scaled ? cx.bead_scale : 1.0f;
-            const float sa = p.pair.sigma_a * sc, sb = p.pair.sigma_b * sc;
-            const float inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f, inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
-            const float cut = p.pair.cutoff * sc, cut2 = cut * cut;
+            const float inv_sa2 = cx.p_inv_sa2, inv_sb2 = cx.p_inv_sb2;
+            const float cut = cx.p_cut, cut2 = cut * cut;
             const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb_ = 24.0f * p.pair.eps_b * inv_sb2;
             const float hca = 0.5f * ca, hcb = 0.5f * cb_, Ai = hca * abi.x, Bi = hcb * abi.y;
             if (role == 0) {

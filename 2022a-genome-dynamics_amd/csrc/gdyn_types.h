@@ -73,8 +73,11 @@ struct CtxF {                   // float copy of DevCtx + block-uniform wall con
     float inv_bond_scale2;
     float near2;                // a bead can touch the wall only if C + 1 >= near2 (see the wall section); <= 0: always
     float w_inv_sa2, w_inv_sb2, w_ca, w_cb;     // soft wall (half diameters, bead scale): 1/s^2, 6 eps_a / sa^2, 24 eps_b / sb^2
+    float p_inv_sa2, p_inv_sb2, p_cut;          // pair potential at the current bead scale: 1/sigma^2 of both cores, cutoff
+    float sg_uniform;                           // sqrt(2 mu kT dt) for the uniform mobility (< 0: per-bead mobilities)
 };
-static_assert(sizeof(CtxF) == 80, "CtxF is staged as 20 dwords");
+#define GD_CTXF_DWORDS 24
+static_assert(sizeof(CtxF) == 4 * GD_CTXF_DWORDS, "CtxF is staged dword by dword (k_step_p)");
 
 struct GridP {                  // per replica cell grid of the last list build
     float org[3];
