@@ -141,7 +141,6 @@ struct gd_system {
     float mob_uniform = -1.f;
     DevBuf<GridP> grid; DevBuf<DevCtx> ctx[2]; DevBuf<float4> react_part[2]; DevBuf<double> epart;   // react_part ping-pongs with ctx
     DevBuf<unsigned long long> lcount_d; DevBuf<float> noise;
-    DevBuf<CtxF> ctxf;             // float context of the coming step (k_ctx -> k_step_p)
     DevBuf<unsigned long long> seeds_d;     // gd_run_desc.replica_seeds of the run in progress
     DevBuf<unsigned> dmax;          // [R] largest squared displacement since the list build (k_step keeps it; zeroed by the build)
     float rn = 0;                   // near-class radius of the tiled list in use
@@ -150,7 +149,6 @@ struct gd_system {
     DevBuf<uint2> sp_out; DevBuf<unsigned long long> sp_count; std::vector<uint2> sp_host;
     bool sp_valid = false; uint32_t sp_r = 0; double sp_dcut = 0; uint64_t sp_serial = 0;
     uint64_t state_serial = 1;     // bumped by everything that changes positions or the model (invalidates the cache)
-    unsigned n_cu = 256;           // compute units of the device: grid of the persistent step kernel
     int ocur = 0;   // which orig[] buffer is current
     std::vector<hipEvent_t> events;
     ~gd_system()
@@ -204,13 +202,12 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
-         s->lcount_d.resize(s->R) == hipSuccess && s->ctxf.resize(s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
+         s->lcount_d.resize(s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess;
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
     gd_launch_identity(s->orig[0].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     if (hipStreamSynchronize(s->stream) != hipSuccess) { delete s; return fail(GD_EHIP, "gd_create: identity kernel failed"); }
-    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && v > 0) s->n_cu = (unsigned)v; }
     *out = s;
     return GD_OK;
 }
@@ -512,7 +509,7 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
     s->adapt = t->adapt_interval;
     if (t->list_width > 0 && t->list_width != s->W) { (void)s->nbr.resize(0); s->W = t->list_width; }
-    if (t->kernel_path > 3) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..3");
+    if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");
     s->kernel_path = t->kernel_path; s->tiled_ok = true; s->tiled_off = 0;
     s->list_valid = false;
     return GD_OK;
@@ -651,7 +648,7 @@ static void fill_common(gd_system *s, StepParams &p)
     p.cpb = s->cpb; p.tile_cap = s->list_tiled ? s->list_tile_cap : s->tile_cap;   // as at the build of the list in use
     p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
     p.meta = s->meta.p; p.rec_x0 = s->rec_x0.p; p.rec_mo = s->rec_mo.p; p.W = s->list_W; p.badj = s->badj.p; p.chain = s->chain.p;
-    p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.ctxf = s->ctxf.p; p.flags = s->flags.p;
+    p.ctx_in = s->ctx[s->ccur].p; p.ctx_out = s->ctx[s->ccur ^ 1].p; p.flags = s->flags.p;
     // wall-reaction partials ping-pong with the context: a launch reads the previous step's partials while its blocks
     // write this step's (one buffer would let late blocks read a mix of two steps)
     p.react_in = s->react_part[s->ccur].p; p.react_out = s->react_part[s->ccur ^ 1].p;
@@ -687,6 +684,7 @@ static void fill_common(gd_system *s, StepParams &p)
     p.has_bend = s->has_bend; p.has_bonds = s->has_bonds;
     p.rv = s->rv; p.rn = s->rn; p.dmax = s->dmax.p; p.term_mask = GD_TERM_ALL;
     if (dev_env("GDYN_FORCE_FAR")) p.rn = 0.f;      // (timing experiments: the far class in every step)
+    if (dev_env("GDYN_FORCE_NEAR")) p.rn = 1e3f;    // (timing experiments with gd_debug_bench only: never the far class -- wrong forces late in an interval)
     p.fout = s->fout.p; p.epart = s->epart.p;
 }
 
@@ -700,7 +698,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
 {
     const bool tiled = with_list && allow_tiled && want_tiled(s);
     if (with_list) {
-        if (s->W == 0) s->W = 96;      // (tiled lists pad the near and the far class to whole chunks separately)
+        if (s->W == 0) s->W = 96;
         s->W = (s->W + GD_UNROLL - 1) & ~(GD_UNROLL - 1);
         const size_t need = (size_t)s->W * s->R * s->Np;   // entries; chunked wave-interleaved layout (k_step)
         // (grown on demand, given back when a dense transient has passed)
@@ -936,11 +934,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 // evaluation of a COMPLETE interval only (a chunk that ends mid-interval records nothing and adapts nothing)
                 p.record_disp = (s->steps_since_build + (uint32_t)q + 1u == s->K);
                 full_interval |= p.record_disp != 0;
-                if (s->kernel_path == 3 && gd_step_p_eligible(p)) {
-                    // (opt-in) persistent, software-pipelined step kernel: the callback state of the step is advanced by k_ctx first
-                    gd_launch_finalize(p, 2, s->stream);
-                    gd_launch_step_p(p, s->n_cu, s->stream);
-                } else gd_launch_step(p, GD_MODE_STEP, s->stream);
+                gd_launch_step(p, GD_MODE_STEP, s->stream);
                 if (s->sw_n) launch_softwell(s, p, 0);
                 s->pcur ^= 1; s->ccur ^= 1;
             }
@@ -1144,7 +1138,6 @@ extern "C" int gd_debug_bench(gd_system *s, int what, int n, double *mean_ms)
     HIPCHK(hipEventRecord(e0, s->stream));
     for (int i = 0; i < n; i++) {
         if (what == 0 || what >= 30) { GDCHK(enqueue_build(s, rv, pair_cutoff(s) > 0)); }
-        else if (s->kernel_path == 3 && gd_step_p_eligible(p)) { gd_launch_finalize(p, 2, s->stream); gd_launch_step_p(p, s->n_cu, s->stream); }
         else gd_launch_step(p, GD_MODE_STEP, s->stream);
     }
     HIPCHK(hipEventRecord(e1, s->stream));

@@ -10,16 +10,14 @@
 //                          ODE; reference 5-sim-genome/src/simulation_interphase/simulation_driver_interphase.cc:12-80) is
 //                          advanced by wave 0 of every block in the prologue of the NEXT launch: no host round trip per step.
 //   k_ctx                  one wave per replica: the pending callback at the end of a chunk, the reaction fold of a force
-//                          evaluation, the per-step context of k_step_p.
-//   k_step_p               (opt-in) persistent, double-buffered form of the tiled step kernel: one workgroup per CU walks
-//                          over tiles, two waves per bead; measured slower than k_step.
+//                          evaluation.
 //   k_softwell             droplet attraction among the few hundred target beads (after k_step; linear in the force).
 //   k_bbox .. k_fill       neighbour search (micromd md::neighbor_searcher; call sites e.g.
 //                          simulation_interphase/contact_map.cc:64-66): bounding box, cell binning, counting sort into
 //                          slot order, tile descriptors, list fill (27-cell sweep from the LDS tile, or from global
 //                          memory on the generic path).
 //   k_pairs                pair search (contact map, glue candidates) filtered from the resident list.
-//   GD_ABL                 timing-only builds (tools/abl.sh): term ablations 11-15, section stamps 30 / 34 / 40.
+//   GD_ABL                 timing-only builds (tools/abl.sh): term ablations 11-15, section stamps 30 / 34.
 //
 // MFMA is not used: the path is an irregular short-range N-body sum.
 #include <hip/hip_fp16.h>
@@ -247,7 +245,7 @@ __device__ __forceinline__ void apply_callback(DevCtx &c, const StepParams &p, u
 }
 
 // Float copy of a replica's context plus the block-uniform wall constants derived from it (CtxF, gdyn_types.h):
-// filled by wave 0 of every k_step block (lane 0), or once per replica and step by k_ctx for k_step_p.
+// filled by wave 0 of every k_step block (lane 0).
 __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepParams &p)
 {
     o.step = c.step;
@@ -321,7 +319,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
     const long long ctx_step0 = p.ctx_in[r].step;
     const int ctx_pending0 = p.ctx_in[r].pending;
     // largest squared displacement of any bead of the replica since the list build, as of the positions this step reads
-    // (kept by the previous steps): decides whether the far class of the lists can matter in this step
+    // (kept by the previous steps): with the bead's own displacement it decides whether the far class of its list can matter in this step
     const float dmax0 = (MODE == GD_MODE_STEP && TILED) ? __uint_as_float(p.dmax[r * GD_DMAX_STRIDE]) : 0.f;
     // ---- prologue (tiled path), ordered for the IN-ORDER vmcnt counter:
     //   1. the thread's (meta, bead id) record -- the one per-bead value the noise needs -- and the tile descriptor
@@ -472,7 +470,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
                 const float lim = 0.5f * (p.rv - cut);
                 if (!(lim > 0.f) || disp2 > lim * lim) p.flags[r * GD_NFLAGS + GD_FLAG_VIOLATION] = 1u;
             }
-            const unsigned cnt = meta >> 16;             // generic path: exact length (tiled: chunk counts nA, nB)
+            const unsigned cnt = meta >> 16;             // generic path: exact length (tiled: chunk count nA)
             // Pair lists are stored in chunks of 16 bytes per bead, wave-interleaved:
             // chunk c of bead g is uint4 #((g/64)*NC + c)*64 + g%64  (one coalesced 1 KiB read per wave).
             // Tiled: 8 x u16 tile indices per chunk; generic: 4 x u32 slots per chunk.
@@ -480,23 +478,30 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
             // The list is padded to a multiple of GD_UNROLL with the bead's own index (zero
             // displacement => zero force), so every batch issues its index loads and its
             // neighbour reads together and the loop body has no bounds test.
-            // Tiled lists: near class in chunks 0 .. nA-1, far class in chunks NCL-1 .. NCL-nB.  The far class was at least
-            // rn away at the build: it can only matter once cutoff + 2 x largest displacement exceeds rn (wave-uniform
-            // test on the replica's running maximum; force / energy evaluations always take both classes).
-            bool use_far = true;
-            if (MODE == GD_MODE_STEP && TILED) { const float h = 0.5f * (p.rn - cut); use_far = !(h > 0.f) || dmax0 > h * h; }
-            const unsigned nch = TILED ? nA + (use_far ? nB : 0u) : 0u;
+            // Tiled lists: near class (d0 < rn at the build) in chunks 0 .. nA-1, far class in chunks NCL-1 .. NCL-nB.  A pair
+            // exerts no force while d0 >= T = cutoff + D_i + D_j (displacements since the build; D_j <= the replica's running
+            // maximum, D_i is this bead's own): the far chunks are walked once T exceeds rn -- the last steps of an interval,
+            // and only by the waves that hold a bead that has moved that far.  Skipped entries have exactly zero force (the
+            // soft cores clamp), so the result does not depend on when the far class joins.  Force / energy evaluations
+            // take both classes.
+            const unsigned nchA = nA;
+            unsigned nchB = nB;
+            if (MODE == GD_MODE_STEP && TILED) {
+                const float T = cut + __builtin_amdgcn_sqrtf(disp2) + __builtin_amdgcn_sqrtf(dmax0);
+                if (T * 1.00005f < p.rn) nchB = 0u;
+            }
+            const unsigned nch = nchA + nchB;
             const unsigned cntp = TILED ? nch * GD_UNROLL : (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
             const unsigned self_e = TILED ? (S16 ? (own_base + local) << 4 : own_base + local) : 0u;     // the padding entries (energy mode skips them)
             // software pipeline: the chunk(s) of the next batch are in flight while one is processed
             // (a second batch of look-ahead bought nothing and costs the registers of one occupancy step)
-            if (TILED && nA == 0u && nch != 0u) qa = nt_load(&lst[(size_t)(NCL - 1u) * 64]);      // (no near chunk: the first one is a far chunk)
+            if (TILED && nchA == 0u && nch != 0u) qa = nt_load(&lst[(size_t)(NCL - 1u) * 64]);      // (no near chunk: the first one is a far chunk)
             for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
                 unsigned jj[GD_UNROLL];
                 float4 xjv[GD_UNROLL];
                 const uint4 q = qa, q0 = qa, q1 = qb;
                 if (k0 + GD_UNROLL < cntp) {
-                    if (TILED) { const unsigned c1 = k0 / 8 + 1; qa = nt_load(&lst[(size_t)(c1 < nA ? c1 : NCL - 1u - (c1 - nA)) * 64]); }
+                    if (TILED) { const unsigned c1 = k0 / 8 + 1; qa = nt_load(&lst[(size_t)(c1 < nchA ? c1 : NCL - 1u - (c1 - nchA)) * 64]); }
                     else { qa = lst[(size_t)(k0 / 4 + 2) * 64]; qb = lst[(size_t)(k0 / 4 + 3) * 64]; }
                 }
                 if (TILED) {
@@ -784,8 +789,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
 }
 
 // One wave per replica.  mode 0: apply the pending callback of the last step (end of a gd_run chunk); mode 1: fold the
-// reaction partials of a force evaluation into the context; mode 2 (before every k_step_p launch): apply the pending
-// callback, publish the float context of the coming step (CtxF) and mark the callback of that step pending.
+// reaction partials of a force evaluation into the context.
 __global__ __launch_bounds__(64) void k_ctx(const StepParams p, int mode)
 {
     const unsigned r = blockIdx.x, lane = threadIdx.x;
@@ -799,10 +803,6 @@ __global__ __launch_bounds__(64) void k_ctx(const StepParams p, int mode)
         c.react[0] = wave_sum_d(rx); c.react[1] = wave_sum_d(ry); c.react[2] = wave_sum_d(rz);
     } else if (c.pending) {
         apply_callback(c, p, r, lane);
-    }
-    if (mode == 2) {
-        if (lane == 0) { CtxF f; fill_ctxf(f, c, p); p.ctxf[r] = f; }
-        c.pending = 1;
     }
     if (lane == 0) p.ctx_out[r] = c;
 }
@@ -851,477 +851,6 @@ void gd_launch_step(const StepParams &p, int mode, hipStream_t st)
 void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st)
 {
     hipLaunchKernelGGL(k_ctx, dim3(p.R), dim3(64), 0, st, p, mode);
-}
-
-// ------------------------------------------------------------------ k_step_p
-// The step kernel of the tiled path in its persistent, software-pipelined form (step mode, byte-offset list entries).
-// One 1024-thread workgroup per CU walks over tiles b = blockIdx.x, + gridDim.x, ... (the same (replica, block) map and
-// XCD affinity as k_step).  Two LDS tile buffers: while tile i is computed from one, the LDS-DMAs of tile i+1 fill the other
-// and every per-thread record / list chunk of tile i+1 is already on its way to registers, so no wave ever waits for
-// memory with nothing else to do -- the k_step prologue (a third of a k_step wave's life) is off the critical path.
-// The 16 waves split each bead's work by ROLE (wave-uniform, no divergence): waves 0-7 (role A) draw the bead's noise,
-// evaluate the even 16-byte list chunks and integrate; waves 8-15 (role B) evaluate the odd chunks, the bonded, bending,
-// point-source and wall terms and hand their partial force over through LDS (the per-bead force sum is a two-wave
-// reduction).  The float context of the step comes from k_ctx (mode 2), staged per tile lane by lane.
-// Synchronisation (cdna_hip_programming.md, "Pipelining across barriers"): all LDS is carved from ONE array; the DMAs
-// of tile i+1 are issued after the barrier that ends every read of their buffer and are retired by the vmcnt(0) in
-// front of the barrier that precedes the first read; barriers inside the loop are raw s_barrier behind an explicit
-// lgkmcnt(0) so that they do not drain the DMAs in flight.
-#define GD_PBLOCK 1024
-#define GD_PF 3                                     // list chunks a role-thread prefetches per tile (2 x 3 x 8 = 48 entries per bead)
-#define GD_P_EXTRA (2 * GD_BLOCK + 32 + 12 + 24 + 16) // float4 beyond the two tiles: 2 x role-B forces, bond table, 2 contexts, 3 descriptors, 2 x reductions
-
-template <bool PERIODIC, int PK, unsigned role>
-__device__ __forceinline__ void step_p_body(const StepParams &p, float4 *const s_all)
-{
-    const unsigned cap = p.tile_cap;
-    float4 *const s_F = s_all + 2 * cap;                                  // [2][GD_BLOCK] partial forces of role B
-    const BondType *const s_bt = (const BondType *)(s_F + 2 * GD_BLOCK);
-    CtxF *const s_ctxf = (CtxF *)(s_F + 2 * GD_BLOCK + 32);               // [2] x 96 B = 12 float4
-    unsigned *const s_desc = (unsigned *)(s_F + 2 * GD_BLOCK + 44);       // [3][32]: a ring -- the descriptor of tile it+1 is written
-                                                                          // while slow waves may still be reading that of tile it-1
-    float *const s_red = (float *)(s_F + 2 * GD_BLOCK + 68);              // [2][8][4]
-
-    const unsigned tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, t = tid & (GD_BLOCK - 1);
-    const unsigned ntile = p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk;
-    const unsigned NCL = p.W / 8, NCB = p.WB / 4;
-    unsigned b = blockIdx.x;
-    if (b >= ntile) return;
-
-    for (unsigned q = tid; q < 2 * GD_MAX_BOND_TYPES; q += GD_PBLOCK) ((uint4 *)(s_F + 2 * GD_BLOCK))[q] = ((const uint4 *)p.btab)[q];
-
-    unsigned r = 0, blk = 0;
-    bool ok = block_map(b, p.nblk, p.cpb, r, blk);
-    if (wid == 0 && lane < 32) s_desc[lane] = ok ? ((const unsigned *)(p.tiles + (size_t)r * p.nblk + blk))[lane] : 0u;
-    __syncthreads();
-
-    // stage tile (rr, .) described by s_desc[d] into buffer `buf`: every wave copies 64 consecutive slots = 1 KiB per DMA
-    auto issue_dma = [&](unsigned d, unsigned buf, unsigned rr) {
-        const float4 *__restrict__ src = p.pos_in + (size_t)rr * p.Np;
-        float4 *dst = s_all + buf * cap;
-#pragma unroll
-        for (int k = 0; k < GD_TILE_RANGES; k++) {
-            const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane((int)s_desc[d * 32 + k]);
-            const unsigned len = (unsigned)__builtin_amdgcn_readfirstlane((int)s_desc[d * 32 + GD_TILE_RANGES + k]);
-            const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)s_desc[d * 32 + 2 * GD_TILE_RANGES + k]);
-            for (unsigned q0 = wid * 64; q0 < len; q0 += GD_PBLOCK) {
-                // Issued from inline asm (cdna_hip_programming.md 5.7): hipcc cannot tell the two tile buffers apart and
-                // would put a vmcnt(0) in front of every LDS access while a DMA it knows of is in flight -- the very
-                // overlap this kernel exists for.  The DMAs are retired by the vmcnt(0) at the top of the loop.
-                if (q0 + lane < len) {
-                    const float4 *gsrc = src + st + q0 + lane;
-                    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) float4 *)(dst + base + q0));
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-                }
-            }
-        }
-    };
-    // the per-thread loads of one tile: (meta, bead id), build position (role A) or first adjacency chunk (role B),
-    // GD_PF list chunks (role A: chunks 0, 2, 4; role B: 1, 3, 5)
-    struct Pre { uint2 mo; uint4 x; uint4 q[GD_PF]; };
-    auto load_pre = [&](Pre &o, unsigned rr, unsigned bb) {
-        const size_t gt = (size_t)rr * p.Np + bb * GD_BLOCK + t;
-        o.mo = p.rec_mo[gt];
-        const uint4 *xs = role == 0 ? (const uint4 *)p.rec_x0 + gt : (const uint4 *)p.badj + (size_t)(gt >> 6) * NCB * 64 + (gt & 63);
-        o.x = *xs;
-        const uint4 *ls = (const uint4 *)p.nbr16 + ((size_t)(gt >> 6) * NCL + role) * 64 + (gt & 63);
-#pragma unroll
-        for (int j = 0; j < GD_PF; j++) o.q[j] = nt_load(ls + (size_t)(2 * j) * 64);
-    };
-
-    Pre cur, nxt;
-    cur.mo = make_uint2(0u, GD_REC_NOBEAD); cur.x = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < GD_PF; j++) cur.q[j] = make_uint4(0, 0, 0, 0);
-    nxt = cur;
-    if (ok) { issue_dma(0, 0, r); load_pre(cur, r, blk); }
-    unsigned bn = b + gridDim.x, rn = 0, blkn = 0;
-    bool has_next = bn < ntile, okn = has_next && block_map(bn, p.nblk, p.cpb, rn, blkn);
-    unsigned dreg = 0, creg = 0;
-    if (wid == 0 && lane < 32 && okn) dreg = ((const unsigned *)(p.tiles + (size_t)rn * p.nblk + blkn))[lane];
-    if (wid == 1 && lane < GD_CTXF_DWORDS && ok) creg = ((const unsigned *)(p.ctxf + r))[lane];
-
-    const float sg_dt = p.dt;
-#if GD_ABL == 40      // timing-only build: shader-clock stamps per loop section, summed per wave (tools/ubench.py GDYN_PSTAMPS=1)
-    unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define GD_PSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pacc_[k] += now_ - pt_; pt_ = now_; } while (0)
-#else
-#define GD_PSTAMP(k) do { } while (0)
-#endif
-    // The last part of a tile -- role A adds role B's partial force, integrates and stores; one thread stores the tile's
-    // wall-reaction partial -- runs at the top of the NEXT iteration, behind the barrier that also publishes role B's LDS
-    // writes: one barrier per tile, and the position stores are old by the time the next vmcnt(0) waits for them (placed
-    // at the end of the iteration they would expose a full store round trip per tile).
-    float3 e_P = make_float3(0.f, 0.f, 0.f), e_F = e_P;      // x + sqrt(2 mu kT dt) z, role A's force
-    float e_w = 0.f, e_disp2 = 0.f;
-    size_t e_g = 0;
-    unsigned e_r = 0, e_blk = 0;
-    bool e_valid = false, e_ok = false;
-    auto epilogue = [&](unsigned eb) {
-        if (role == 0) {
-            if (e_valid) {
-                // ---- overdamped Langevin / Euler-Maruyama (a1): x += mu F dt + sqrt(2 mu kT dt) xi
-                const float4 fb = s_F[eb * GD_BLOCK + t];
-                float mu = p.mob_uniform;
-                if (mu < 0.f) { mu = p.mob[e_g]; asm volatile("" : "+v"(mu)); }
-                const float mu_dt = mu * sg_dt;
-                p.pos_out[e_g] = make_float4(e_P.x + mu_dt * (e_F.x + fb.x), e_P.y + mu_dt * (e_F.y + fb.y), e_P.z + mu_dt * (e_F.z + fb.z), e_w);
-            }
-            if (p.record_disp) {
-                const float m = wave_max_f(e_disp2);
-                if (lane == 0 && e_ok) atomicMax(&p.flags[e_r * GD_NFLAGS + GD_FLAG_MAXDISP2], __float_as_uint(m));
-            }
-        } else if (tid == GD_BLOCK && e_ok && p.wall.enabled) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int w = 0; w < GD_BLOCK / 64; w++) { v.x += s_red[(eb * 8 + w) * 4 + 0]; v.y += s_red[(eb * 8 + w) * 4 + 1]; v.z += s_red[(eb * 8 + w) * 4 + 2]; }
-            p.react_out[(size_t)e_r * p.nblk + e_blk] = v;
-        }
-    };
-    // A plain global load inside the loop (rare paths only) is consumed right where it is issued: otherwise the compiler
-    // carries "load pending" state for its registers into the common path and drains the DMAs in flight there
-#define GD_CONSUME4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
-    for (unsigned it = 0;; it++) {
-        const unsigned cb = it & 1u;
-        GD_PSTAMP(0);     // loop tail
-        // ---- tile `it` has landed: its DMAs and per-thread loads were issued one iteration ago
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) alone (a builtin: the compiler's own wait bookkeeping sees it)
-        GD_PSTAMP(1);     // wait for the tile's loads and DMAs
-        const unsigned ds = it % 3u, dsn = (it + 1u) % 3u;      // descriptor slots of this tile and the next
-        if (wid == 0 && lane < 32) s_desc[dsn * 32 + lane] = dreg;
-        if (wid == 1 && lane < GD_CTXF_DWORDS) ((unsigned *)(s_ctxf + cb))[lane] = creg;
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) alone
-        __builtin_amdgcn_s_barrier();
-        GD_PSTAMP(2);     // barrier
-        if (it > 0) epilogue(cb ^ 1u);
-        GD_PSTAMP(3);     // epilogue of the previous tile
-        // ---- everything tile it+1 needs goes on its way now
-        unsigned bnn = 0, rnn = 0, blknn = 0;
-        bool has_nn = false, oknn = false;
-        if (has_next) {
-            if (okn) { issue_dma(dsn, cb ^ 1u, rn); load_pre(nxt, rn, blkn); }
-            bnn = bn + gridDim.x; has_nn = bnn < ntile; oknn = has_nn && block_map(bnn, p.nblk, p.cpb, rnn, blknn);
-            dreg = 0; creg = 0;
-            if (wid == 0 && lane < 32 && oknn) dreg = ((const unsigned *)(p.tiles + (size_t)rnn * p.nblk + blknn))[lane];
-            if (wid == 1 && lane < GD_CTXF_DWORDS && okn) creg = ((const unsigned *)(p.ctxf + rn))[lane];
-        }
-
-        GD_PSTAMP(4);     // prefetch issue
-        // ---- compute tile (r, blk) from buffer cb
-        const char *const tb = (const char *)(s_all + cb * cap);
-        const float4 *const tile = s_all + cb * cap;
-        const CtxF &cx = s_ctxf[cb];
-        const unsigned own_base = s_desc[ds * 32 + GD_TD_OWN], tile_ok = s_desc[ds * 32 + GD_TD_NRANGES];
-        const size_t rbase = (size_t)r * p.Np;
-        const float4 *__restrict__ rpos = p.pos_in + rbase;
-        const size_t gt = rbase + blk * GD_BLOCK + t;
-        const unsigned local = (cur.mo.x >> 12) & 0x1ffu, nA = (cur.mo.x >> 21) & 31u, nB = (cur.mo.x >> 26) & 31u, oid = cur.mo.y;
-        const bool valid = ok && oid != GD_REC_NOBEAD;
-        const size_t g = rbase + blk * GD_BLOCK + (valid ? local : 0u);
-        float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (__builtin_amdgcn_readfirstlane((int)tile_ok) != 0) { if (valid) xi4 = tile[own_base + local]; }
-        else if (valid) { xi4 = p.pos_in[g]; GD_CONSUME4(xi4); }      // truncated tile (the host rolls the chunk back)
-        const float3 xi = make_float3(xi4.x, xi4.y, xi4.z);
-        const float2 abi = unpack_ab(xi4.w);
-        float3 F = make_float3(0.f, 0.f, 0.f);
-
-        // Brownian noise (role A), before the pair loop: independent of the tile
-        float3 z = make_float3(0.f, 0.f, 0.f);
-        if (role == 0 && valid && p.kT > 0.f) {
-            if (p.noise_mode == NOISE_PHILOX) z = p.seeds ? philox_normal3(p.seeds[r], oid, cx.step + 1, 0u) : philox_normal3(p.seed, oid, cx.step + 1, r);
-            else if (p.noise_mode == NOISE_HOST) {
-                const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
-                float zx = h[0], zy = h[1], zz = h[2];
-                asm volatile("" : "+v"(zx), "+v"(zy), "+v"(zz));
-                z = make_float3(zx, zy, zz);
-            }
-        }
-
-        GD_PSTAMP(5);     // own position + noise
-        // ---- non-bonded pairs: this role's chunks of the Verlet list (a3, a5)
-        float disp2 = 0.f;
-        if (valid && p.pair.enabled) {
-            const float inv_sa2 = cx.p_inv_sa2, inv_sb2 = cx.p_inv_sb2;
-            const float cut = cx.p_cut, cut2 = cut * cut;
-            const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb_ = 24.0f * p.pair.eps_b * inv_sb2;
-            const float hca = 0.5f * ca, hcb = 0.5f * cb_, Ai = hca * abi.x, Bi = hcb * abi.y;
-            if (role == 0) {
-                // Verlet-skin check: the list is complete for this force evaluation iff every bead moved less than
-                // (rv - cutoff) / 2 since the build
-                const float4 x0 = make_float4(__uint_as_float(cur.x.x), __uint_as_float(cur.x.y), __uint_as_float(cur.x.z), 0.f);
-                const float dx = xi.x - x0.x, dy = xi.y - x0.y, dz = xi.z - x0.z;
-                disp2 = dx * dx + dy * dy + dz * dz;
-                const float lim = 0.5f * (p.rv - cut);
-                if (!(lim > 0.f) || disp2 > lim * lim) p.flags[r * GD_NFLAGS + GD_FLAG_VIOLATION] = 1u;
-            }
-            const bool mix = (PK == 1) || (PK == 0 && p.pair.mix != 0);
-            // chunks in use: the near class (0 .. nA-1) followed by the far class (NCL-1 downwards); this kernel always
-            // takes both.  The role takes every second chunk of that sequence; the first GD_PF of them are prefetched on the
-            // assumption that they are near chunks (which have the sequence index as their chunk index)
-            const unsigned nch = nA + nB;
-            // one 16-byte chunk = 8 entries, evaluated as two groups of four LDS gathers (the register budget of four
-            // waves per SIMD: two tiles' worth of prefetched records and chunks stay live across the loop)
-            auto half = [&](const unsigned e0, const unsigned e1) {
-                unsigned jj[4];
-                float4 xjv[4];
-                jj[0] = e0 & 0xffffu; jj[1] = e0 >> 16; jj[2] = e1 & 0xffffu; jj[3] = e1 >> 16;
-#pragma unroll
-                for (int u = 0; u < 4; u++) xjv[u] = *(const float4 *)(tb + jj[u]);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float4 xj = xjv[u];
-                    float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
-                    if (PERIODIC) d = min_image(d, p.box, p.inv_box);
-                    const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                    if (PK != 0) {
-                        float waca = ca, wbcb = cb_;
-                        if (PK == 1) {
-                            const float2 abj = unpack_ab(xj.w);
-                            waca = fmaf(abj.x, hca, Ai); wbcb = fmaf(abj.y, hcb, Bi);
-                        }
-                        const float f = softcore_2383(r2, inv_sa2, inv_sb2, waca, wbcb);
-                        F.x = fmaf(f, d.x, F.x); F.y = fmaf(f, d.y, F.y); F.z = fmaf(f, d.z, F.z);
-                    } else if (r2 < cut2) {
-                        float wa = 1.0f, wb = 1.0f;
-                        if (mix) { const float2 abj = unpack_ab(xj.w); wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y); }
-                        float ea, fa, eb, fb;
-                        softcore(p.pair.eps_a, inv_sa2, p.pair.p_a, p.pair.q_a, r2, ea, fa);
-                        softcore(p.pair.eps_b, inv_sb2, p.pair.p_b, p.pair.q_b, r2, eb, fb);
-                        const float f = wa * fa + wb * fb;
-                        F.x += f * d.x; F.y += f * d.y; F.z += f * d.z;
-                    }
-                }
-            };
-            auto chunk = [&](const uint4 q) { half(q.x, q.y); half(q.z, q.w); };
-            const uint4 *ls = (const uint4 *)p.nbr16 + (size_t)(gt >> 6) * NCL * 64 + (gt & 63);
-            auto fetch = [&](unsigned k) { uint4 q = ls[(size_t)(k < nA ? k : NCL - 1u - (k - nA)) * 64]; GD_CONSUME4(q); return q; };   // plain load
-            if (role < nch) chunk(role < nA ? cur.q[0] : fetch(role));
-            if (role + 2u < nch) chunk(role + 2u < nA ? cur.q[1] : fetch(role + 2u));
-            if (role + 4u < nch) chunk(role + 4u < nA ? cur.q[2] : fetch(role + 4u));
-            for (unsigned k = role + 2u * GD_PF; k < nch; k += 2u) chunk(fetch(k));     // beyond the prefetched chunks (rare)
-        }
-
-        GD_PSTAMP(6);     // pairs
-        float3 react = make_float3(0.f, 0.f, 0.f);
-        if (role == 1 && valid) {
-            const unsigned deg = cur.mo.x & 0xffu;
-            // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
-            if (p.has_bonds) {
-                const float inv_bs2 = cx.inv_bond_scale2;
-                const uint4 *__restrict__ adj = (const uint4 *)p.badj + (size_t)(gt >> 6) * NCB * 64 + (gt & 63);
-                for (unsigned k0 = 0; k0 < deg; k0 += 4) {
-                    uint4 aq = cur.x;
-                    if (k0 != 0) { aq = adj[(size_t)(k0 >> 2) * 64]; GD_CONSUME4(aq); }
-                    const unsigned ents[4] = {aq.x, aq.y, aq.z, aq.w};
-                    float4 xjs[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        xjs[u] = xi4;
-                        if (k0 + u < deg) {
-                            const unsigned j = ents[u] & GD_ADJ_MASK;
-                            if (ents[u] & GD_ADJ_LOCAL) xjs[u] = tile[j]; else { xjs[u] = rpos[j]; GD_CONSUME4(xjs[u]); }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (k0 + u >= deg) break;
-                        const unsigned ent = ents[u];
-                        const BondType bt = s_bt[(ent >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1)];
-                        const float4 xj = xjs[u];
-                        float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
-                        if (PERIODIC && (bt.flags & 4)) d = min_image(d, p.box, p.inv_box);
-                        const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                        float K = bt.ka, l = bt.la;
-                        if (bt.flags & 1) {
-                            const float2 abj = unpack_ab(xj.w);
-                            const float a = 0.5f * (abi.x + abj.x), bb = 0.5f * (abi.y + abj.y);
-                            K = a * bt.ka + bb * bt.kb; l = a * bt.la + bb * bt.lb;
-                        }
-                        if (bt.flags & 2) { K = K * inv_bs2; l = l * cx.bond_scale; }
-                        float e = 0.f, fr;
-                        if (p.has_softcore_bonds && bt.kind == POT_SOFTCORE) {
-                            softcore(K, 1.0f / (l * l), bt.pq & 0xff, bt.pq >> 8, r2, e, fr);
-                        } else {
-                            const float inv_d = r2 > 0.0f ? __builtin_amdgcn_rsqf(r2) : 0.0f;
-                            const float x = fmaxf(fmaf(r2, inv_d, -l), bt.xmin);
-                            fr = -K * x * inv_d;
-                        }
-                        F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
-                    }
-                }
-            }
-            // ---- cosine bending over the (up to) three triplets this bead belongs to (a7)
-            if (p.has_bend) {
-                float4 be = p.bendE[g];
-                GD_CONSUME4(be);
-                if (be.x != 0.f || be.y != 0.f || be.z != 0.f) {
-                    int4 c4 = p.chain[g];
-                    GD_CONSUME4(c4);
-                    float3 xm2 = xi, xm1 = xi, xp1 = xi, xp2 = xi;
-                    auto fetch = [&](int c) -> float3 {
-                        float4 v;
-                        if (c & GD_CHAIN_LOCAL) v = tile[c & 0xffff]; else { v = rpos[c]; GD_CONSUME4(v); }
-                        return make_float3(v.x, v.y, v.z);
-                    };
-                    if (c4.x >= 0) xm2 = fetch(c4.x);
-                    if (c4.y >= 0) xm1 = fetch(c4.y);
-                    if (c4.z >= 0) xp1 = fetch(c4.z);
-                    if (c4.w >= 0) xp2 = fetch(c4.w);
-                    float3 fi, fk; float cs;
-                    if (be.x != 0.f) {
-                        const float3 d1 = make_float3(xm1.x - xm2.x, xm1.y - xm2.y, xm1.z - xm2.z);
-                        const float3 d2 = make_float3(xi.x - xm1.x, xi.y - xm1.y, xi.z - xm1.z);
-                        if (bend_forces(d1, d2, be.x, fi, fk, cs)) { F.x += fk.x; F.y += fk.y; F.z += fk.z; }
-                    }
-                    if (be.y != 0.f) {
-                        const float3 d1 = make_float3(xi.x - xm1.x, xi.y - xm1.y, xi.z - xm1.z);
-                        const float3 d2 = make_float3(xp1.x - xi.x, xp1.y - xi.y, xp1.z - xi.z);
-                        if (bend_forces(d1, d2, be.y, fi, fk, cs)) { F.x -= fi.x + fk.x; F.y -= fi.y + fk.y; F.z -= fi.z + fk.z; }
-                    }
-                    if (be.z != 0.f) {
-                        const float3 d1 = make_float3(xp1.x - xi.x, xp1.y - xi.y, xp1.z - xi.z);
-                        const float3 d2 = make_float3(xp2.x - xp1.x, xp2.y - xp1.y, xp2.z - xp1.z);
-                        if (bend_forces(d1, d2, be.z, fi, fk, cs)) { F.x += fi.x; F.y += fi.y; F.z += fi.z; }
-                    }
-                }
-            }
-            // ---- point sources (a8)
-            if (p.nps > 0) {
-                const unsigned pm = (cur.mo.x >> 8) & 0xfu;
-                for (int q = 0; q < p.nps; q++) {
-                    if (!((pm >> q) & 1u)) continue;
-                    const float3 d = make_float3(xi.x - p.ps[q].p[0], xi.y - p.ps[q].p[1], xi.z - p.ps[q].p[2]);
-                    const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                    float e, fr;
-                    bond_pot(p.ps[q].kind, p.ps[q].k, p.ps[q].b, 2, 1, r2, e, fr);
-                    F.x += fr * d.x; F.y += fr * d.y; F.z += fr * d.z;
-                }
-            }
-        }
-        // ---- ellipsoid wall (a9) and inner sphere, role B (wave-level early-outs: all lanes take part in the ballots)
-        if (role == 1 && p.wall.enabled) {
-            const float ia = cx.inv_semi2[0], ib = cx.inv_semi2[1], ic = cx.inv_semi2[2];
-            const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);
-            const float C1 = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z, C = C1 - 1.0f;
-            if (__builtin_amdgcn_ballot_w64(valid && C1 >= cx.near2) != 0ull) {
-                const float B = s1.x * s1.x + s1.y * s1.y + s1.z * s1.z;
-                const float A = s1.x * s1.x * ia + s1.y * s1.y * ib + s1.z * s1.z * ic;
-                const float den = B + __builtin_amdgcn_sqrtf(fmaxf(B * B - A * C, 0.f));
-                if (valid && den > 0.f && C != 0.f) {
-                    const float u = C * __builtin_amdgcn_rcpf(den);
-                    const float3 dl = make_float3(u * s1.x, u * s1.y, u * s1.z);
-                    const float r2 = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z;
-                    float fr = 0.f;
-                    if (C < 0.f) {
-                        const float wa = 0.5f * (abi.x + p.wall.wall_a), wb = 0.5f * (abi.y + p.wall.wall_b);
-                        if (p.wall.fast2383) fr = softcore_2383(r2, cx.w_inv_sa2, cx.w_inv_sb2, wa * cx.w_ca, wb * cx.w_cb);
-                        else {
-                            float ea, fa, eb, fb;
-                            softcore(p.wall.eps_a, cx.w_inv_sa2, p.wall.p_a, p.wall.q_a, r2, ea, fa);
-                            softcore(p.wall.eps_b, cx.w_inv_sb2, p.wall.p_b, p.wall.q_b, r2, eb, fb);
-                            fr = wa * fa + wb * fb;
-                        }
-                    } else fr = -p.wall.packing_spring;
-                    if (fr != 0.f) {
-                        const float3 fw = make_float3(fr * dl.x, fr * dl.y, fr * dl.z);
-                        F.x += fw.x; F.y += fw.y; F.z += fw.z;
-                        react.x = -fw.x * (xi.x - dl.x) * cx.inv_semi[0];
-                        react.y = -fw.y * (xi.y - dl.y) * cx.inv_semi[1];
-                        react.z = -fw.z * (xi.z - dl.z) * cx.inv_semi[2];
-                    }
-                }
-            }
-        }
-        if (role == 1 && p.wall.inner_enabled) {
-            const float rr2 = xi.x * xi.x + xi.y * xi.y + xi.z * xi.z;
-            const float reach = p.wall.in_radius + 0.5f * fmaxf(p.wall.in_sigma_a, p.wall.in_sigma_b);
-            if (__builtin_amdgcn_ballot_w64(valid && rr2 < reach * reach) != 0ull && valid && rr2 > 0.f) {
-                const float inv_r = rsqrtf(rr2), rad = rr2 * inv_r, gap = rad - p.wall.in_radius;
-                const float r2 = gap * gap, gs = gap * inv_r;
-                float fr = 0.f;
-                if (gap > 0.f) {
-                    const float sa = 0.5f * p.wall.in_sigma_a, sb = 0.5f * p.wall.in_sigma_b;
-                    const float wa = 0.5f * (abi.x + p.wall.in_wall_a), wb = 0.5f * (abi.y + p.wall.in_wall_b);
-                    float ea, fa, eb, fb;
-                    softcore(p.wall.in_eps_a, sa > 0.f ? 1.0f / (sa * sa) : 0.f, p.wall.in_p_a, p.wall.in_q_a, r2, ea, fa);
-                    softcore(p.wall.in_eps_b, sb > 0.f ? 1.0f / (sb * sb) : 0.f, p.wall.in_p_b, p.wall.in_q_b, r2, eb, fb);
-                    fr = wa * fa + wb * fb;
-                } else if (gap < 0.f) fr = -p.wall.in_spring;
-                F.x += fr * gs * xi.x; F.y += fr * gs * xi.y; F.z += fr * gs * xi.z;
-            }
-        }
-        GD_PSTAMP(7);     // bonded, wall
-        // ---- role B hands its partial force over; wall-reaction partial of the tile (deterministic order)
-        if (role == 1) {
-            s_F[cb * GD_BLOCK + t] = make_float4(F.x, F.y, F.z, 0.f);
-            if (p.wall.enabled) {
-                const float sx = wave_sum_f(react.x), sy = wave_sum_f(react.y), sz = wave_sum_f(react.z);
-                if (lane == 0) { s_red[(cb * 8 + wid - 8) * 4 + 0] = sx; s_red[(cb * 8 + wid - 8) * 4 + 1] = sy; s_red[(cb * 8 + wid - 8) * 4 + 2] = sz; }
-            }
-        } else {
-            float mu = p.mob_uniform;                         // (the noise amplitude needs the mobility now; the drift term later)
-            if (mu < 0.f && valid) { mu = p.mob[g]; asm volatile("" : "+v"(mu)); }
-            const float sg = sqrtf(2.0f * p.kT * mu * sg_dt);
-            e_P = make_float3(xi.x + sg * z.x, xi.y + sg * z.y, xi.z + sg * z.z);
-            e_F = F; e_w = xi4.w; e_disp2 = disp2; e_g = g; e_valid = valid;
-        }
-        e_r = r; e_blk = blk; e_ok = ok;
-        if (!has_next) break;
-        b = bn; r = rn; blk = blkn; ok = okn; cur = nxt;
-        bn = bnn; rn = rnn; blkn = blknn; has_next = has_nn; okn = oknn;
-    }
-#if GD_ABL == 40
-    if (lane == 0) {
-        unsigned long long *rec = (unsigned long long *)p.fout + ((size_t)blockIdx.x * (GD_PBLOCK / 64) + wid) * 16;
-        for (int q = 0; q < 12; q++) rec[q] = pacc_[q];
-        rec[15] = 1ull;
-    }
-#endif
-    // the last tile
-    const unsigned last = (ntile - 1u - blockIdx.x) / gridDim.x;        // index of this workgroup's last iteration
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-    epilogue(last & 1u);
-}
-#undef GD_CONSUME4
-
-// The two roles run the same loop (same barriers) from separate instantiations: each keeps only its own state in
-// registers (the budget of four waves per SIMD is 128 VGPRs).
-template <bool PERIODIC, int PK>
-__global__ __launch_bounds__(GD_PBLOCK) void k_step_p(const StepParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 s_all[];
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9)) == 0) step_p_body<PERIODIC, PK, 0u>(p, s_all);
-    else step_p_body<PERIODIC, PK, 1u>(p, s_all);
-}
-
-bool gd_step_p_eligible(const StepParams &p)
-{
-    return p.tiled && p.tile_cap < 4096u && p.W >= 8u * 2u * GD_PF && p.W <= GD_TILED_MAX_W &&
-           (2u * (size_t)p.tile_cap + GD_P_EXTRA) * sizeof(float4) <= 160u * 1024u;
-}
-
-void gd_launch_step_p(const StepParams &p, unsigned n_cu, hipStream_t st)
-{
-    const unsigned ntile = p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk;
-    unsigned g = n_cu < ntile ? n_cu : ntile;
-    if (g > GD_XCDS) g -= g % GD_XCDS;       // a multiple of the XCD count: tile b and b + grid stay on one XCD
-    const size_t lds = (2u * (size_t)p.tile_cap + GD_P_EXTRA) * sizeof(float4);
-    static bool once = false;
-    if (!once) {
-        once = true;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step_p<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step_p<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step_p<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step_p<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step_p<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step_p<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-#define LP(PER, PK) hipLaunchKernelGGL((k_step_p<PER, PK>), dim3(g), dim3(GD_PBLOCK), lds, st, p)
-    if (p.periodic) { if (p.pk == 1) LP(true, 1); else if (p.pk == 2) LP(true, 2); else LP(true, 0); }
-    else { if (p.pk == 1) LP(false, 1); else if (p.pk == 2) LP(false, 2); else LP(false, 0); }
-#undef LP
 }
 
 // --------------------------------------------------------- neighbour search
@@ -2097,7 +1626,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
         if (tid < sizeof(TileDesc) / 4) ((unsigned *)&s_td)[tid] = src[tid];
         __syncthreads();
     }
-    unsigned slot = blk * GD_BLOCK + tid, cnt = 0, nA = 0;      // tiled: cnt = entries of both classes, padding included
+    unsigned slot = blk * GD_BLOCK + tid, cnt = 0, nA = 0;      // tiled: cnt = entries of the row, padding included
     bool valid = slot < p.N;
     if (TILED) {
         const uint2 mo = p.rec_mo[gt];

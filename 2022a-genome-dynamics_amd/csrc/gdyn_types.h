@@ -48,7 +48,7 @@ struct TileDesc {   // all fields 32-bit: the kernels read it through a block-un
     unsigned total;                        // beads staged
     unsigned nranges;                      // merged ranges in use (0: the tile did not fit)
     unsigned own_base;                     // LDS index of the block's first own slot (blk * GD_BLOCK): k_step reads its beads from the tile
-    unsigned pad_[2];                      // (the first 32 dwords are what k_step_p stages per tile)
+    unsigned pad_[2];
     // per (dz,dy) row offset k: first slot of cell c0+off_k-1 and its LDS index (0xffffffff: no such row)
     unsigned kstart[GD_TILE_RANGES];
     unsigned kbase[GD_TILE_RANGES];
@@ -66,7 +66,7 @@ struct DevCtx {                 // per replica, fp64 (a few scalars; kept exact)
     double react[3];            // axial_reaction of the last force evaluation
 };
 
-struct CtxF {                   // float copy of DevCtx + block-uniform wall constants; 80 bytes = 20 dwords (k_step_p stages it lane by lane)
+struct CtxF {                   // float copy of DevCtx + block-uniform wall constants; one per block in LDS
     long long step;
     float bead_scale, bond_scale, semi[3];
     float inv_semi[3], inv_semi2[3];
@@ -76,8 +76,6 @@ struct CtxF {                   // float copy of DevCtx + block-uniform wall con
     float p_inv_sa2, p_inv_sb2, p_cut;          // pair potential at the current bead scale: 1/sigma^2 of both cores, cutoff
     float sg_uniform;                           // sqrt(2 mu kT dt) for the uniform mobility (< 0: per-bead mobilities)
 };
-#define GD_CTXF_DWORDS 24
-static_assert(sizeof(CtxF) == 4 * GD_CTXF_DWORDS, "CtxF is staged dword by dword (k_step_p)");
 
 struct GridP {                  // per replica cell grid of the last list build
     float org[3];
@@ -162,7 +160,6 @@ struct StepParams {
     // context
     const DevCtx *ctx_in;
     DevCtx *ctx_out;
-    CtxF *ctxf;                         // [R] float context of the coming step (k_ctx mode 2 -> k_step_p)
     const float4 *react_in;             // [R][nblk] wall-reaction partials of the previous step (read by the callback)
     float4 *react_out;                  // [R][nblk] this step's partials (double-buffered with the context)
     unsigned *flags;
@@ -243,9 +240,7 @@ struct BuildParams {
 
 // launchers (gdyn_kernels.hip)
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
-void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st);     // k_ctx: 0 final callback, 1 fold reaction partials, 2 per-step (k_step_p)
-bool gd_step_p_eligible(const StepParams &p);
-void gd_launch_step_p(const StepParams &p, unsigned n_cu, hipStream_t st);
+void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st);     // k_ctx: 0 final callback, 1 fold reaction partials
 void gd_launch_build(const BuildParams &p, hipStream_t st);
 // Droplet attraction among a small set of target beads (gd_set_pair_softwell): all pairs, one thread per target.
 struct SoftwellP {

@@ -289,8 +289,7 @@ typedef struct {
     uint32_t adapt_interval;    /* 1 = adapt interval from measured displacements */
     uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
     uint32_t kernel_path;       /* 0 auto (LDS-tiled where the tiles fit, else generic), 1 generic (global-gather lists),
-                                   2 LDS-tiled (needs fp16-exact a/b factors), 3 LDS-tiled with the persistent, double-buffered
-                                   step kernel (k_step_p; experimental: measured slower than 2 on MI355X) */
+                                   2 LDS-tiled (needs fp16-exact a/b factors) */
 } gd_tuning;
 
 int gd_set_tuning(gd_system *sys, const gd_tuning *t);

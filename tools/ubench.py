@@ -10,7 +10,9 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 EQ = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 snap = f"/tmp/snap_{R}_{EQ}.npy"
 s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
-if os.path.exists(snap):
+if os.environ.get("GDYN_STATE"):      # relaxed positions written by `bench.py --save-state` (the benchmark's own state)
+    s.set_positions(np.load(os.environ["GDYN_STATE"]))
+elif os.path.exists(snap):
     s.set_positions(np.load(snap))
 else:
     s.begin_phase(); s.run(EQ, 1e-5, 1.0, seed=99, flags=0); np.save(snap, s.positions())
@@ -28,7 +30,3 @@ if os.environ.get("GDYN_FSTAMPS"):
     vals = [s.debug_bench(30 + k, 10) for k in range(7)]
     print("   lane-0 test groups per wave %.1f, append iterations %.1f" % (s.debug_bench(38, 10) / 10, s.debug_bench(39, 10) / 10))
     print("   k_fill cycles/wave: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
-if os.environ.get("GDYN_PSTAMPS"):
-    names = ["tail", "vmcnt-wait", "barrier", "epilogue", "prefetch-issue", "own+noise", "pairs", "bonds+wall"]
-    vals = [s.debug_bench(10 + k, 20) for k in range(8)]
-    print("   k_step_p cycles/wave (all tiles): " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, vals)) + f"  sum {sum(vals):.0f}")
