@@ -100,11 +100,23 @@ __device__ __forceinline__ float softcore_2383_energy(float r2, float inv_sa2, f
     return wa * ea * ga * ga * ga + wb * eb * gb * gb * gb;
 }
 
+// Wave reductions over all 64 lanes by DPP (row shifts inside the rows of 16, then the row broadcasts): six fused
+// add / max instructions and one v_readlane instead of six ds_bpermute round trips through the LDS crossbar.  All lanes
+// must be active; the result is wave-uniform.  Lanes without a source keep the identity 0 (sums; maxima of non-negative values).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp0(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum_f(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp0<0x111, 0xf>(v);      // row_shr:1
+    v += dpp0<0x112, 0xf>(v);      // row_shr:2
+    v += dpp0<0x114, 0xf>(v);      // row_shr:4
+    v += dpp0<0x118, 0xf>(v);      // row_shr:8
+    v += dpp0<0x142, 0xa>(v);      // row_bcast:15 into rows 1, 3
+    v += dpp0<0x143, 0xc>(v);      // row_bcast:31 into rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v)
 {
@@ -112,11 +124,15 @@ __device__ __forceinline__ double wave_sum_d(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max_f(float v)
+__device__ __forceinline__ float wave_max_f(float v)      // v >= 0
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp0<0x111, 0xf>(v));
+    v = fmaxf(v, dpp0<0x112, 0xf>(v));
+    v = fmaxf(v, dpp0<0x114, 0xf>(v));
+    v = fmaxf(v, dpp0<0x118, 0xf>(v));
+    v = fmaxf(v, dpp0<0x142, 0xa>(v));
+    v = fmaxf(v, dpp0<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // u2^(n/2) for even n in {0,2,4,6,10}
@@ -760,7 +776,8 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
     // waves still raise it)
     const float rwave = record ? wave_max_f(disp2) : 0.f;
     if (p.wall.enabled && MODE != GD_MODE_ENERGY) {
-        const float sx = wave_sum_f(react.x), sy = wave_sum_f(react.y), sz = wave_sum_f(react.z);
+        float sx = 0.f, sy = 0.f, sz = 0.f;      // (waves of interior beads have nothing to add)
+        if (__builtin_amdgcn_ballot_w64(react.x != 0.f || react.y != 0.f || react.z != 0.f) != 0ull) { sx = wave_sum_f(react.x); sy = wave_sum_f(react.y); sz = wave_sum_f(react.z); }
         if (lane == 0) { s_red[wid][0] = sx; s_red[wid][1] = sy; s_red[wid][2] = sz; s_red[wid][3] = record ? rwave : dwave; }
         __syncthreads();
         if (tid == 0) {
