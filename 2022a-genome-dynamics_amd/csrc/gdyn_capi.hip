@@ -674,7 +674,7 @@ static void fill_common(gd_system *s, StepParams &p)
         p.wall.in_p_a = w.p_a; p.wall.in_q_a = w.q_a; p.wall.in_p_b = w.p_b; p.wall.in_q_b = w.q_b;
         p.wall.in_wall_a = (float)w.wall_a_factor; p.wall.in_wall_b = (float)w.wall_b_factor; p.wall.in_spring = (float)w.spring;
     }
-    p.scaling = ScaleP{s->has_scaling ? 1 : 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau};
+    p.scaling = ScaleP{s->has_scaling ? 1 : 0, 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau, 0.0, 0.0};
     p.btab = s->btab.p; p.nbt = (int)s->n_bond_types; p.has_softcore_bonds = s->has_softcore_bonds ? 1 : 0;
     p.nps = (int)s->psrc.size();
     for (int q = 0; q < p.nps; q++) {
@@ -905,6 +905,18 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         GDCHK(clear_flags(s));
 
         StepParams p;
+        // The scales a callback sets are pure functions of the step index (simulation_driver_interphase.cc:42-43): when every
+        // replica is at the same step (the usual case) the host evaluates them and passes them with the launch
+        bool common_step = s->has_scaling && (run->flags & GD_RUN_UPDATE_SCALES);
+        const long long step0 = s->hctx[0].step;
+        for (uint32_t r = 1; r < s->R && common_step; r++) common_step = s->hctx[r].step == step0;
+        auto host_scales = [&](StepParams &q, int64_t launch) {      // launch: index within the chunk of the launch that applies the callback
+            if (!common_step) return;
+            const double time = (double)(step0 + launch) * run->timestep;
+            q.scaling.from_host = 1;
+            q.scaling.bead_next = scale_at(s, s->bs_init, s->bs_tau, time);
+            q.scaling.bond_next = scale_at(s, s->bo_init, s->bo_tau, time);
+        };
         size_t nev = 0;
         float step_ms = 0, build_ms = 0;
         std::vector<std::pair<size_t, int>> spans;   // event index, kind (0 step, 1 build)
@@ -930,6 +942,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 p.seeds = run->replica_seeds ? s->seeds_d.p : nullptr;
                 p.noise_mode = run->noise_mode; p.run_flags = run->flags;
                 p.host_noise = host_noise ? s->noise.p + (size_t)(done + k + q) * RN * 3 : nullptr;
+                host_scales(p, k + q);
                 // the interval adaptation needs the displacement at K steps since the build: recorded at the last force
                 // evaluation of a COMPLETE interval only (a chunk that ends mid-interval records nothing and adapts nothing)
                 p.record_disp = (s->steps_since_build + (uint32_t)q + 1u == s->K);
@@ -947,6 +960,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         // apply the callback of the last step, then check the chunk
         fill_common(s, p);
         p.dt_d = run->timestep; p.dt = (float)run->timestep; p.run_flags = run->flags;
+        host_scales(p, chunk);
         gd_launch_finalize(p, 0, s->stream);
         s->ccur ^= 1;
         hipEvent_t ev_end = get_event(s, nev++);

@@ -118,11 +118,25 @@ __device__ __forceinline__ float wave_sum_f(float v)
     v += dpp0<0x143, 0xc>(v);      // row_bcast:31 into rows 2, 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp0_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp0_d<0x111, 0xf>(v);
+    v += dpp0_d<0x112, 0xf>(v);
+    v += dpp0_d<0x114, 0xf>(v);
+    v += dpp0_d<0x118, 0xf>(v);
+    v += dpp0_d<0x142, 0xa>(v);
+    v += dpp0_d<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ float wave_max_f(float v)      // v >= 0
 {
@@ -249,8 +263,11 @@ __device__ __forceinline__ void apply_callback(DevCtx &c, const StepParams &p, u
     c.step += 1;
     c.time = (double)c.step * p.dt_d;
     if ((p.run_flags & RUN_UPDATE_SCALES) && p.scaling.enabled) {
-        c.bead_scale = 1.0 - (1.0 - p.scaling.bead_init) * exp(-c.time / p.scaling.bead_tau);
-        c.bond_scale = 1.0 - (1.0 - p.scaling.bond_init) * exp(-c.time / p.scaling.bond_tau);
+        if (p.scaling.from_host) { c.bead_scale = p.scaling.bead_next; c.bond_scale = p.scaling.bond_next; }      // (pure functions of the step index)
+        else {
+            c.bead_scale = 1.0 - (1.0 - p.scaling.bead_init) * exp(-c.time / p.scaling.bead_tau);
+            c.bond_scale = 1.0 - (1.0 - p.scaling.bond_init) * exp(-c.time / p.scaling.bond_tau);
+        }
     }
     c.react[0] = rx; c.react[1] = ry; c.react[2] = rz;
     if ((p.run_flags & RUN_WALL_DYNAMICS) && p.wall.enabled) {
@@ -267,7 +284,7 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
     o.step = c.step;
     o.bead_scale = (float)c.bead_scale; o.bond_scale = (float)c.bond_scale;
     o.semi[0] = (float)c.semi[0]; o.semi[1] = (float)c.semi[1]; o.semi[2] = (float)c.semi[2];
-    o.inv_bond_scale2 = (float)(1.0 / (c.bond_scale * c.bond_scale));
+    o.inv_bond_scale2 = 1.0f / ((float)c.bond_scale * (float)c.bond_scale);
     o.near2 = 0.f; o.w_inv_sa2 = 0.f; o.w_inv_sb2 = 0.f; o.w_ca = 0.f; o.w_cb = 0.f;
     {   // block-uniform constants of the pair term and of the integrator: divisions and the square root once per block
         const float sc = p.pair.scaled ? (float)c.bead_scale : 1.0f;

@@ -121,7 +121,10 @@ struct PointSrc {
 
 struct ScaleP {
     int enabled;
+    int from_host;              // 1: every replica is at the same step, so the scales the pending callback sets were computed by the host
+                                //    (two fp64 exponentials less on the critical path of every block's first wave)
     double bead_init, bead_tau, bond_init, bond_tau;
+    double bead_next, bond_next;       // bead_scale / bond_scale of the step the pending callback moves to (from_host)
 };
 
 struct StepParams {
