@@ -682,7 +682,7 @@ static void fill_common(gd_system *s, StepParams &p)
         for (int k = 0; k < 3; k++) p.ps[q].p[k] = (float)s->psrc[q].p[k];
     }
     p.has_bend = s->has_bend; p.has_bonds = s->has_bonds;
-    p.rv = s->rv; p.rn = s->rn; p.dmax = s->dmax.p; p.term_mask = GD_TERM_ALL;
+    p.rv = s->rv; p.rn = s->sw_n ? 0.f : s->rn; p.dmax = s->dmax.p; p.term_mask = GD_TERM_ALL;      // (the droplet kernel moves beads after k_step has bounded their displacement: both list classes then)
     if (dev_env("GDYN_FORCE_FAR")) p.rn = 0.f;      // (timing experiments: the far class in every step)
     if (dev_env("GDYN_FORCE_NEAR")) p.rn = 1e3f;    // (timing experiments with gd_debug_bench only: never the far class -- wrong forces late in an interval)
     p.fout = s->fout.p; p.epart = s->epart.p;

@@ -1200,25 +1200,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t rbase = (size_t)r * p.Np;
-    // Tiled path: k_step's THREADS are ordered by the list length their bead had at the previous build (a very good
-    // predictor of the new one), longest first, so that the 64 lanes of a k_step wave run the same number of list
-    // batches.  This kernel still works slot by slot (neighbouring slots share their row windows: broadcast LDS reads, equal
-    // trip counts), but writes each bead's list, adjacency chunks and record at the position gt of the k_step thread
-    // that will own it.
     const unsigned slot = blk * GD_BLOCK + threadIdx.x;
     size_t gt = rbase + slot;
-    if (TILED) {
-        __shared__ unsigned s_hist[32], s_off[32];
-        if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
-        __syncthreads();
-        unsigned bin = 31u;                                        // slots past N: last
-        if (slot < p.N) bin = 30u - min((unsigned)p.len_prev[(size_t)r * p.N + p.orig_out[rbase + slot]], 30u);
-        const unsigned rank = atomicAdd(&s_hist[bin], 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) { unsigned run = 0; for (int b = 0; b < 32; b++) { s_off[b] = run; run += s_hist[b]; } }
-        __syncthreads();
-        gt = rbase + blk * GD_BLOCK + s_off[bin] + rank;
-    }
     const size_t g = rbase + slot;
     const float4 *__restrict__ rpos = p.pos_out + rbase;
     // block-uniform descriptor, read through a uniform pointer (scalar loads; a local copy indexed in
@@ -1229,6 +1212,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     // store), so it is copied once into LDS (188 bytes) and read from there.
     __shared__ TileDesc s_tdesc;
 #define s_td s_tdesc
+    const unsigned o_pre = (TILED && slot < p.N) ? p.orig_out[g] : 0u;      // (issued ahead of the DMAs: the balancing key below depends on it)
     if (TILED && GD_ABL != 4) {
         // LDS-DMA staging as in k_step: descriptor by scalar loads first, then all pieces back to back
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
@@ -1245,9 +1229,26 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             }
         }
     }
-    if (TILED) {       // (after the DMA issue in program order: the copy's wait then coincides with the barrier's)
-        if (threadIdx.x < sizeof(TileDesc) / 4) ((unsigned *)&s_tdesc)[threadIdx.x] = ((const unsigned *)tdp)[threadIdx.x];
+    // Tiled path: k_step's THREADS are ordered by the list length their bead had at the previous build (a very good
+    // predictor of the new one), longest first, so that the 64 lanes of a k_step wave run the same number of list
+    // batches.  This kernel still works slot by slot (neighbouring slots share their row windows: broadcast LDS reads, equal
+    // trip counts), but writes each bead's list, adjacency chunks and record at the position gt of the k_step thread
+    // that will own it.
+    if (TILED) {
+        // (two barriers: histogram cleared + descriptor copied | histogram complete; every wave then scans the 32 bins itself.
+        // The first barrier also waits for the tile DMAs issued above.)
+        __shared__ unsigned s_hist[32];
+        if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+        if (threadIdx.x >= 64 && threadIdx.x - 64 < sizeof(TileDesc) / 4) ((unsigned *)&s_tdesc)[threadIdx.x - 64] = ((const unsigned *)tdp)[threadIdx.x - 64];
+        unsigned bin = 31u;                                        // slots past N: last
+        if (slot < p.N) bin = 30u - min((unsigned)p.len_prev[(size_t)r * p.N + o_pre], 30u);
         __syncthreads();
+        const unsigned rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        unsigned incl = s_hist[lane & 31u];
+        const unsigned own = incl;
+        for (int o = 1; o < 32; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)(lane & 31u) >= o) incl += v; }
+        gt = rbase + blk * GD_BLOCK + (unsigned)__shfl((int)(incl - own), (int)bin, 64) + rank;
     }
     GD_FSTAMP(0);     // staging + barrier
     unsigned cnt = 0;
