@@ -562,9 +562,9 @@ static int finalize_topology(gd_system *s)
     for (size_t i = 0; i < types.size(); i++) {
         const gd_bond_params &p = types[i];
         const bool harmonic = p.kind == GD_POT_HARMONIC;     // U = K r^2 / 2 is the spring with rest length 0
-        bt[i] = BondType{(float)p.k_a, (float)p.k_b, harmonic ? 0.f : (float)p.l_a, harmonic ? 0.f : (float)p.l_b, p.kind,
-                         (p.mix ? 1 : 0) | (p.scale_by_bond_scale ? 2 : 0) | (p.minimum_image ? 4 : 0) | (terms[i] << 8), p.p | (p.q << 8),
-                         p.kind == GD_POT_SEMISPRING ? 0.f : -3.0e38f};
+        bt[i] = BondType{(float)p.k_a, (float)p.k_b, harmonic ? 0.f : (float)p.l_a, harmonic ? 0.f : (float)p.l_b,
+                         (p.mix ? 1 : 0) | (p.scale_by_bond_scale ? 2 : 0) | (p.minimum_image ? 4 : 0) | (terms[i] << 8),
+                         p.kind == GD_POT_SEMISPRING ? 0.f : -3.0e38f, p.kind, p.p | (p.q << 8)};
         if (p.kind == GD_POT_SOFTCORE) s->has_softcore_bonds = true;
     }
     // bending: energy of the triplet starting at each bead

@@ -590,6 +590,66 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) 
         if (GD_ABL != 13 && p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
             const unsigned deg = meta & 0xffu;
             const float inv_bs2 = s_ctx.inv_bond_scale2;
+            if (TILED) {
+                // Tiled path, branch-free: two adjacency entries per batch, their partner positions and bond-type records all
+                // requested from LDS before the first is used (one round of latency per batch, no divergent branches).  An entry
+                // beyond the bead's degree stands for the bead itself (zero separation: zero force from every bond form); partners
+                // outside the tile are a rare, wave-uniform detour through global memory.
+                const unsigned own_idx = own_base + local;
+                for (unsigned k0 = 0; k0 < deg; k0 += 4) {
+                    const uint4 aq = k0 == 0 ? adj0 : adj[(size_t)(k0 >> 2) * 64];
+                    const unsigned ents4[4] = {aq.x, aq.y, aq.z, aq.w};
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if (h == 1 && __builtin_amdgcn_ballot_w64(k0 + 2u < deg) == 0ull) break;
+                        float4 xjs[2], ta[2];
+                        float2 tb[2];
+                        unsigned ty[2];
+                        bool on[2], away = false;
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            on[u] = k0 + 2u * h + u < deg;
+                            const unsigned e = on[u] ? ents4[2 * h + u] : GD_ADJ_LOCAL;
+                            const bool loc = (e & GD_ADJ_LOCAL) != 0u;
+                            xjs[u] = s_tile[(on[u] && loc) ? (e & GD_ADJ_MASK) : own_idx];
+                            ty[u] = (e >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1);
+                            ta[u] = *(const float4 *)&s_bt[ty[u]];
+                            tb[u] = *(const float2 *)&s_bt[ty[u]].flags;
+                            away |= !loc;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(away) != 0ull) {
+#pragma unroll
+                            for (int u = 0; u < 2; u++)
+                                if (on[u] && !(ents4[2 * h + u] & GD_ADJ_LOCAL)) xjs[u] = rpos[ents4[2 * h + u] & GD_ADJ_MASK];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const float4 xj = xjs[u];
+                            const unsigned flags = __float_as_uint(tb[u].x);
+                            float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
+                            if (PERIODIC && (flags & 4u)) d = min_image(d, p.box, p.inv_box);
+                            const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                            const float2 abj = unpack_ab(xj.w);
+                            const bool mixed = (flags & 1u) != 0u, scaled = (flags & 2u) != 0u;
+                            const float a = mixed ? 0.5f * (abi.x + abj.x) : 1.0f, b = mixed ? 0.5f * (abi.y + abj.y) : 0.0f;
+                            const float K = (a * ta[u].x + b * ta[u].y) * (scaled ? inv_bs2 : 1.0f);
+                            const float l = (a * ta[u].z + b * ta[u].w) * (scaled ? s_ctx.bond_scale : 1.0f);
+                            // harmonic / spring / semispring in one form: elongation x = r - l clamped from below
+                            const float inv_d = r2 > 0.0f ? __builtin_amdgcn_rsqf(r2) : 0.0f;     // hardware rsq, 1 ulp
+                            const float x = fmaxf(fmaf(r2, inv_d, -l), tb[u].y);
+                            float fr = -K * x * inv_d, e = 0.f;
+                            if (MODE == GD_MODE_ENERGY) e = 0.5f * K * x * x;
+                            if (p.has_softcore_bonds && s_bt[ty[u]].kind == POT_SOFTCORE) {      // (rare bond form; uniform test first)
+                                const int pq = s_bt[ty[u]].pq;
+                                softcore(K, 1.0f / (l * l), pq & 0xff, pq >> 8, r2, e, fr);
+                            }
+                            if (MODE != GD_MODE_STEP && !(mask & (flags >> 8))) { fr = 0.f; e = 0.f; }
+                            F.x = fmaf(fr, d.x, F.x); F.y = fmaf(fr, d.y, F.y); F.z = fmaf(fr, d.z, F.z);
+                            if (MODE == GD_MODE_ENERGY && on[u]) E += 0.5f * e;
+                        }
+                    }
+                }
+            } else
             // four adjacency entries (one 16-byte chunk) per round: the partner positions are fetched together, so
             // their LDS / global latencies overlap instead of adding up bond by bond
             for (unsigned k0 = 0; k0 < deg; k0 += 4) {

@@ -105,13 +105,13 @@ struct WallP {
     int in_p_a, in_q_a, in_p_b, in_q_b;
 };
 
-struct BondType {               // 32 bytes: two 16-byte LDS reads per bond
+struct BondType {               // 32 bytes: a 16-byte and an 8-byte LDS read per bond (kind / pq only on the rare soft-core path)
     float ka, kb, la, lb;
-    int kind;
     int flags;                  // mix | scaled << 1 | minimg << 2 | term << 8
-    int pq;                     // p | q << 8 (GD_POT_SOFTCORE)
     float xmin;                 // lower clamp of the elongation r - l: 0 for the semispring, -inf otherwise
                                 // (harmonic = spring with l = 0, so one branch-free form covers the three)
+    int kind;
+    int pq;                     // p | q << 8 (GD_POT_SOFTCORE)
 };
 
 struct PointSrc {
