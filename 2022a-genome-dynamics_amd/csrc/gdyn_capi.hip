@@ -751,7 +751,7 @@ static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (siz
 static unsigned pick_tile_cap(unsigned need)
 {
     // LDS is granted in 1280-byte granules (measured with 1184 B of static LDS: 3264 entries fit 3 blocks, 3318 do not; 720 B now)
-    static std::vector<unsigned> caps = {3312u, 4080u, 5072u, 8192u};      // (4080: the largest tile of the persistent step kernel, byte-offset entries)
+    static std::vector<unsigned> caps = {3312u, 4080u, 5072u, 8192u};      // (4080: the largest tile with byte-offset list entries)
     static bool init = false;
     if (!init) {      // experiment hook: GDYN_TILE_CAPS=a,b,c
         if (const char *e = dev_env("GDYN_TILE_CAPS")) { caps.clear(); for (const char *q = e; *q;) { caps.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
