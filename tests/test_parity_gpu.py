@@ -385,6 +385,32 @@ def test_many_tiles_trajectory_matches_oracle(hip, oracle):
         assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), rtol=0, atol=2e-9), r
 
 
+def test_callback_scales_host_and_device_paths(hip, oracle):
+    """The scales a callback sets are pure functions of the step index: with every replica at the same step the host
+    evaluates them (same libm exp as the oracle: identical bits); replicas at different steps make the device evaluate
+    them (fp64 exp of the device library: 1e-12).  Both against the oracle, with the trajectories."""
+    _, kw, dt, kT, flags = CASES["genome"]
+    for different in (False, True):
+        R = 3
+        sh, _ = wl.genome_interphase(hip, n_replicas=R, **kw)
+        so, _ = wl.genome_interphase(oracle, n_replicas=R, **kw)
+        for s in (sh, so):
+            s.begin_phase()
+            if different:
+                for r in range(R):
+                    c = s.context(r)
+                    s.set_context(r, 1000 * r, c.bead_scale, c.bond_scale, tuple(c.semiaxes))
+            s.run(12, dt, kT, seed=SEED, flags=flags)
+        for r in range(R):
+            ch, co = sh.context(r), so.context(r)
+            assert ch.step == co.step == (1000 * r if different else 0) + 12
+            if different:
+                assert abs(ch.bead_scale - co.bead_scale) <= 1e-12 and abs(ch.bond_scale - co.bond_scale) <= 1e-12
+            else:
+                assert ch.bead_scale == co.bead_scale and ch.bond_scale == co.bond_scale
+        assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
+
+
 # ---------------------------------------------------------------- BASELINE sizes
 
 def test_full_size_genome_properties(hip):
