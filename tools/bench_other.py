@@ -10,6 +10,7 @@ which = sys.argv[1]
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 skin = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+path = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 if which == "1kb":
     s, info = wl.chromatin_1kb(hip, n_beads=250000, n_replicas=R); flags = 0
 elif which == "spindle":
@@ -19,7 +20,7 @@ elif which == "genome62k":
 elif which == "abbox":
     s, info = wl.ab_box(hip, n_replicas=R); flags = 0
 dt, kT = info["timestep"], info["temperature"]
-if skin > 0: s.set_tuning(skin=skin)
+if skin > 0 or path: s.set_tuning(skin=skin, kernel_path=path)
 s.begin_phase()
 s.run(max(steps // 2, 100), dt, kT, seed=5, flags=0)
 s.begin_phase()
@@ -28,4 +29,4 @@ t0 = time.perf_counter(); tm = s.run(steps, dt, kT, seed=7, flags=flags); el = t
 c = s.context(); N = info["n_beads"]
 print(json.dumps({"workload": info["workload"], "replicas": R, "bead_steps_per_s": N * R * steps / el, "ms_per_step": el / steps * 1e3,
                   "step_kernel_ms": tm.step_kernel_ms / tm.step_launches, "rebuild_ms_per_step": tm.rebuild_ms / tm.step_launches,
-                  "L_per_bead": c.list_entries / N, "K": c.rebuild_interval, "rollbacks": c.rollbacks, "E_per_bead": float(s.energy().mean() / N)}))
+                  "list_path": c.list_path, "L_per_bead": c.list_entries / N, "K": c.rebuild_interval, "rollbacks": c.rollbacks, "E_per_bead": float(s.energy().mean() / N)}))
