@@ -327,7 +327,10 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
 // S16 (tiled lists only): entries are BYTE offsets into the tile (tile capacity < 4096 entries), one decode
 // instruction per entry instead of mask + shift-add
 template <int MODE, bool PERIODIC, bool TILED, int PK, bool S16>
-__global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? 6 : 1) void k_step(const StepParams p)      // tiled stepping: three
+#ifndef GD_STEP_WAVES
+#define GD_STEP_WAVES 6      // waves per SIMD the tiled step kernel is compiled for (6 = three 512-thread blocks per CU = at most 80 VGPRs)
+#endif
+__global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? GD_STEP_WAVES : 1) void k_step(const StepParams p)      // tiled stepping: three
                                                                                      // blocks per CU = 6 waves per SIMD = at most 80 VGPRs
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
