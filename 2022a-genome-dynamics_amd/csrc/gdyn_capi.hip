@@ -965,8 +965,14 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         s->ccur ^= 1;
         hipEvent_t ev_end = get_event(s, nev++);
         HIPCHK(hipEventRecord(ev_end, s->stream));
-        std::vector<unsigned> f;
-        GDCHK(read_flags(s, f));
+        // one round trip for everything the host wants from the chunk: flags, contexts, list counts
+        std::vector<unsigned> f((size_t)s->R * GD_NFLAGS);
+        std::vector<DevCtx> ctx_new(s->R);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(f.data(), s->flags.p, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(ctx_new.data(), s->ctx[s->ccur].p, s->R * sizeof(DevCtx), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->lcount.data(), s->lcount_d.p, s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
         bool violated = false; float maxd2 = 0;
         for (uint32_t r = 0; r < s->R; r++) {
             violated |= f[r * GD_NFLAGS + GD_FLAG_VIOLATION] != 0;
@@ -1007,8 +1013,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         }
         HIPCHK(hipEventElapsedTime(&ms, ev_begin, ev_end));
         s->timing.total_ms += ms; s->timing.step_kernel_ms += step_ms; s->timing.rebuild_ms += build_ms;
-        GDCHK(download_ctx(s));
-        HIPCHK(hipMemcpy(s->lcount.data(), s->lcount_d.p, s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        s->hctx = ctx_new;
         unsigned long long L = 0;
         for (auto v : s->lcount) L += v;
         s->timing.list_entries_visited += L * (uint64_t)chunk;   // L of the last build, per step
