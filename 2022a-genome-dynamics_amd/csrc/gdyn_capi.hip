@@ -898,7 +898,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     int64_t done = 0;
     while (done < run->steps) {
         // ---- one verified chunk
-        const int64_t chunk = std::min<int64_t>(run->steps - done, std::min<int64_t>(256, std::max<int64_t>(32, 6ll * s->K)));
+        const int64_t chunk = std::min<int64_t>(run->steps - done, std::min<int64_t>(256, std::max<int64_t>(32, 12ll * s->K)));
         // snapshot for rollback: positions in bead order + context
         gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->snap.p, s->N, s->Np, s->R, 0, s->stream);
         const std::vector<DevCtx> snap_ctx = s->hctx;
