@@ -962,28 +962,56 @@ void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st)
 
 // --------------------------------------------------------- neighbour search
 
-// per-block bounding box partials (open box): bbox[(r*nblk + blk)*6 + {lo xyz, hi xyz}]
+// bounding box partials (open box): bbox[(r*nblk + blk)*6 + {lo xyz, hi xyz}].  One block covers FOUR chunks of 512 slots (four
+// loads in flight per thread: the pass is latency-bound) and writes its partial into the first of their four entries, the neutral
+// element into the others.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dppi(float v, float ident)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax(float v)      // all 64 lanes active; result in every lane
+{
+    const float id = MAX ? -INFINITY : INFINITY;
+#define GD_MM(a, b) (MAX ? fmaxf(a, b) : fminf(a, b))
+    v = GD_MM(v, (dppi<0x111, 0xf>(v, id))); v = GD_MM(v, (dppi<0x112, 0xf>(v, id))); v = GD_MM(v, (dppi<0x114, 0xf>(v, id)));
+    v = GD_MM(v, (dppi<0x118, 0xf>(v, id))); v = GD_MM(v, (dppi<0x142, 0xa>(v, id))); v = GD_MM(v, (dppi<0x143, 0xc>(v, id)));
+#undef GD_MM
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __global__ __launch_bounds__(GD_BLOCK) void k_bbox(const BuildParams p)
 {
     __shared__ float s_lo[GD_BLOCK / 64][3], s_hi[GD_BLOCK / 64][3];
-    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
-    const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned nb4 = (p.nblk + 3u) / 4u;
+    const unsigned r = blockIdx.x / nb4, blk0 = (blockIdx.x % nb4) * 4u;
+    const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    if (slot < p.N) {
-        const float4 x = p.pos_in[(size_t)r * p.Np + slot];
-        lo[0] = hi[0] = x.x; lo[1] = hi[1] = x.y; lo[2] = hi[2] = x.z;
+    float4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned slot = (blk0 + i) * GD_BLOCK + threadIdx.x;
+        x[i] = slot < p.N ? p.pos_in[(size_t)r * p.Np + slot] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool on = (blk0 + i) * GD_BLOCK + threadIdx.x < p.N;
+        lo[0] = fminf(lo[0], x[i].x); lo[1] = fminf(lo[1], x[i].y); lo[2] = fminf(lo[2], x[i].z);
+        if (on) { hi[0] = fmaxf(hi[0], x[i].x); hi[1] = fmaxf(hi[1], x[i].y); hi[2] = fmaxf(hi[2], x[i].z); }
     }
     for (int k = 0; k < 3; k++) {
-        for (int o = 32; o > 0; o >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64)); }
-        if (lane == 0) { s_lo[wid][k] = lo[k]; s_hi[wid][k] = hi[k]; }
+        const float l = wave_minmax<false>(lo[k]), h = wave_minmax<true>(hi[k]);
+        if (lane == 0) { s_lo[wid][k] = l; s_hi[wid][k] = h; }
     }
     __syncthreads();
     if (threadIdx.x < 3) {
         const int k = threadIdx.x;
         float l = s_lo[0][k], h = s_hi[0][k];
         for (int w = 1; w < GD_BLOCK / 64; w++) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
-        p.bbox[((size_t)r * p.nblk + blk) * 6 + k] = l;
-        p.bbox[((size_t)r * p.nblk + blk) * 6 + 3 + k] = h;
+        for (unsigned i = 0; i < 4u && blk0 + i < p.nblk; i++) {
+            p.bbox[((size_t)r * p.nblk + blk0 + i) * 6 + k] = i == 0 ? l : INFINITY;
+            p.bbox[((size_t)r * p.nblk + blk0 + i) * 6 + 3 + k] = i == 0 ? h : -INFINITY;
+        }
     }
 }
 
@@ -1622,7 +1650,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 void gd_launch_build(const BuildParams &p, hipStream_t st)
 {
     const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk);
-    if (!p.periodic) hipLaunchKernelGGL(k_bbox, grid, block, 0, st, p);
+    if (!p.periodic) hipLaunchKernelGGL(k_bbox, dim3(p.R * ((p.nblk + 3u) / 4u)), block, 0, st, p);
     hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(64), 0, st, p);
     if (p.periodic) hipLaunchKernelGGL(k_bin<true>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(k_bin<false>, grid, block, 0, st, p);
