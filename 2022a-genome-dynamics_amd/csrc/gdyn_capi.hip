@@ -144,6 +144,8 @@ struct gd_system {
     DevBuf<unsigned long long> seeds_d;     // gd_run_desc.replica_seeds of the run in progress
     DevBuf<unsigned> dmax;          // [R] largest squared displacement since the list build (k_step keeps it; zeroed by the build)
     float rn = 0;                   // near-class radius of the tiled list in use
+    double a2_ema = 0;              // running mean of (largest displacement)^2 per step of an interval (interval adaptation; 0: none yet)
+    double last_dt = 0, last_kT = -1;
     double near_frac = 0.65;        // near-class radius = cutoff + near_frac x (list radius - cutoff)
     // gd_search_pairs: device output, counters, and the cached result of the last call
     DevBuf<uint2> sp_out; DevBuf<unsigned long long> sp_count; std::vector<uint2> sp_host;
@@ -507,6 +509,7 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
     if (t->skin > 0) s->skin = t->skin;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
+    s->a2_ema = 0;
     s->adapt = t->adapt_interval;
     if (t->list_width > 0 && t->list_width != s->W) { (void)s->nbr.resize(0); s->W = t->list_width; }
     if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");
@@ -875,6 +878,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     if ((run->flags & GD_RUN_UPDATE_SCALES) && !s->has_scaling) return fail(GD_ESTATE, "gd_run: scale updates requested without gd_set_scaling");
     GDCHK(prepare(s));
     s->state_serial++;
+    if (run->timestep != s->last_dt || run->temperature != s->last_kT) { s->a2_ema = 0; s->last_dt = run->timestep; s->last_kT = run->temperature; }   // another regime: measure afresh
     const bool with_list = pair_cutoff(s) > 0;
     const size_t RN = (size_t)s->R * s->N;
     memset(&s->timing, 0, sizeof s->timing);
@@ -992,7 +996,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 if (s->K == 1) {
                     if (s->skin > 8) return fail(GD_ESTATE, "gd_run: Verlet skin cannot cover one step (timestep too large?)");
                     s->skin *= 1.5;
-                } else { s->K_bad = s->K; s->K_bad_ttl = 64; s->K = std::max(1u, s->K - std::max(1u, s->K / 4)); }   // (a gentler cut, K/8 for 32 chunks, violates again sooner: measured 1% slower)
+                } else { s->K_bad = s->K; s->K_bad_ttl = 64; s->K = std::max(1u, s->K - std::max(1u, s->K / 4)); s->a2_ema = 0; }   // (a gentler cut, K/8 for 32 chunks, violates again sooner: measured 1% slower)
             }
             s->timing.step_launches -= std::min<uint64_t>(s->timing.step_launches, (uint64_t)chunk);
             continue;
@@ -1021,12 +1025,16 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             const double cut_now = pair_cutoff(s) * (s->pair.scale_by_bead_scale ? bead_scale_bound(s, nullptr, 0) : 1.0);
             const double lim = 0.5 * (s->rv - cut_now), d = std::sqrt((double)maxd2);
             if (lim > 0 && d > 0) {
-                // displacement grows ~ sqrt(steps): aim at 85% of the skin at the end of an interval. The maximum over ~2e6 beads
-                // fluctuates by only ~3.5% between intervals (sigma / sqrt(2 ln n)), so 15% is a 4-sigma margin; a violation
-                // costs one rolled-back chunk and is remembered (K_bad)
-                const double ratio = d / lim;
-                static const double target = dev_env("GDYN_K_TARGET") ? atof(dev_env("GDYN_K_TARGET")) : 0.85;
-                double knew = (double)s->K * (target / ratio) * (target / ratio);
+                // displacement grows ~ sqrt(steps): aim at 90% of the skin at the end of an interval. The maximum over ~2e6 beads
+                // fluctuates by only ~3.5% between intervals (sigma / sqrt(2 ln n)) and the measurement is the largest of a chunk's
+                // (up to 12) intervals, averaged over chunks, i.e. already biased upwards: measured on the benchmark state no rollback
+                // in 40 000 steps at 0.90, the first ones at 0.92; a violation costs one rolled-back chunk and is remembered (K_bad)
+                // (the squared displacement per step of an interval, d^2 / K, is averaged over the chunks -- weight 0.4 for the newest --
+                // so that the interval does not jitter with the single measurement: 12 ... 15 on the benchmark state otherwise)
+                const double a2 = d * d / (double)s->K;
+                s->a2_ema = s->a2_ema > 0 ? 0.6 * s->a2_ema + 0.4 * a2 : a2;
+                static const double target = dev_env("GDYN_K_TARGET") ? atof(dev_env("GDYN_K_TARGET")) : 0.90;
+                double knew = target * lim * target * lim / s->a2_ema;
                 knew = std::min(knew, 2.0 * s->K + 1);
                 s->K = (uint32_t)std::max(1.0, std::min(200.0, std::floor(knew)));
             } else if (d == 0) s->K = std::min(200u, s->K * 2);
