@@ -1360,11 +1360,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         unsigned listlen = 0, nA = 0, nB = 0;
         const unsigned o = p.orig_out[g];
         const unsigned *so = p.slot_of + (size_t)r * p.N;
+        const unsigned nr_tile = TILED ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_td.nranges) : 0u;      // (merged ranges in use: three, typically)
         auto to_local = [&](unsigned ps, unsigned &idx) -> bool {   // slot -> tile index
-#pragma unroll
-            for (int k = 0; k < GD_TILE_RANGES; k++) {
+            for (unsigned k = 0; k < nr_tile; k++) {
                 const unsigned d = ps - s_td.start[k];
-                if (k < (int)s_td.nranges && d < s_td.len[k]) { idx = s_td.base[k] + d; return true; }
+                if (d < s_td.len[k]) { idx = s_td.base[k] + d; return true; }
             }
             return false;
         };
@@ -1436,16 +1436,18 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     w0 = w1; w1 = w2; w2 = w3; w3 = j;
                 }
                 cnt++;
-                if (cnt % PER == 0 && cnt + cntB <= p.W) {
-                    flush();                                   // (only if a second chunk fills before the next flush point)
-                    p0 = w0; p1 = w1; p2 = w2; p3 = w3; pend = cnt / PER;
+                if (cnt % PER == 0) {
+                    if (cnt + cntB <= p.W) {
+                        flush();                               // (only if a second chunk fills before the next flush point)
+                        p0 = w0; p1 = w1; p2 = w2; p3 = w3; pend = cnt / PER;
+                    }
                 }
             };
             auto push_far = [&](unsigned j) {                  // (tiled only; far chunks are few: stored as they fill)
                 b0 = __builtin_amdgcn_alignbit(b1, b0, 16); b1 = __builtin_amdgcn_alignbit(b2, b1, 16);
                 b2 = __builtin_amdgcn_alignbit(b3, b2, 16); b3 = __builtin_amdgcn_alignbit(j, b3, 16);
                 cntB++;
-                if (cntB % 8u == 0 && ((cnt + 7u) & ~7u) + cntB <= p.W) lst[(size_t)(NC - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3);
+                if (cntB % 8u == 0) { if (((cnt + 7u) & ~7u) + cntB <= p.W) lst[(size_t)(NC - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3); }
             };
             if (TILED && PERIODIC) {
                 // periodic tile = whole rows: for each of the 9 wrapped (dz,dy) rows the x-window cx-1..cx+1 is one
