@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBGDYN_PATH = os.path.join(_HERE, "csrc", os.environ.get("GDYN_LIB", "libgdyn.so"))
+LIBGDYN_PATH = os.path.join(_HERE, "csrc", "libgdyn.so")      # the product library; the package reads no environment variable
 
 GD_BOX_OPEN, GD_BOX_PERIODIC = 0, 1
 POT_HARMONIC, POT_SPRING, POT_SEMISPRING, POT_SOFTCORE = 0, 1, 2, 3
@@ -165,9 +165,16 @@ class Lib:
 _product = None
 
 
-def load():
-    """Load the HIP product library. Raises if the extension has not been built."""
+def load(path=None):
+    """Load the HIP product library (or, for developer builds, the HIP library at `path`: a file name is looked up in
+    csrc/).  Raises if the extension has not been built."""
     global _product
+    if path:
+        path = path if os.path.sep in path else os.path.join(_HERE, "csrc", path)
+        lib = Lib(path)
+        if lib.backend != "hip":
+            raise ImportError(f"{path} reports backend {lib.backend!r}, expected 'hip'")
+        return lib
     if _product is None:
         if not os.path.exists(LIBGDYN_PATH):
             raise ImportError(
@@ -353,7 +360,7 @@ class System:
         """Developer builds only (csrc/gdyn_dev.h, libgdyn_dev.so): kernel micro-benchmark on the current state."""
         f = getattr(self.lib.dll, "gd_debug_bench", None)
         if f is None:
-            raise GdynError(6, "gd_debug_bench: not in this library (developer builds only: make -C csrc dev, GDYN_LIB=libgdyn_dev.so)")
+            raise GdynError(6, "gd_debug_bench: not in this library (developer builds only: make -C csrc dev; load('libgdyn_dev.so'))")
         f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         ms = C.c_double(0)
         self.lib.check(f(self._h, what, n, C.byref(ms)))

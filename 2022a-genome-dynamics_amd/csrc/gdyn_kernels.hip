@@ -347,6 +347,17 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     const unsigned tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t rbase = (size_t)r * p.Np;
     const float4 *__restrict__ rpos = p.pos_in + rbase;
+#if GD_ABL == 43 || GD_ABL == 44
+    if (blockIdx.x < 768u) {      // stagger the first round of blocks by their wave slot (first / second / third block of the CU)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        const unsigned k = (hwid & 0xfu) >> 1;
+        for (unsigned i = 0; i < k && i < 3u; i++) { __builtin_amdgcn_s_sleep(127); if (GD_ABL == 44) __builtin_amdgcn_s_sleep(127); }
+    }
+#endif
+#if GD_ABL == 40
+    __builtin_amdgcn_s_setprio(3);
+#endif
 
     // every independent per-bead load is issued up front, ahead of the tile staging and the barrier,
     // so their latencies overlap (the kernel is latency-bound, not ALU-bound)
@@ -468,7 +479,13 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         if (lane == 0) fill_ctxf(s_ctx, c, p);
     }
     GD_STAMP(0);      // prologue: loads issued, tile DMA issued, noise
+#if GD_ABL == 40
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
+#if GD_ABL == 41
+    __builtin_amdgcn_s_setprio(2);
+#endif
     GD_STAMP(1);      // barrier (tile arrival)
     if (TILED) {
         valid = oid != GD_REC_NOBEAD;
@@ -559,6 +576,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                 for (int u = uh; u < uh + GD_HALF; u++) {
                     if (GD_ABL == 22) xjv[u] = s_tile[(threadIdx.x + 64u * u + k0) & 2047u];          // conflict-free LDS reads
                     else if (GD_ABL == 23) xjv[u] = make_float4(xi.x + 0.01f * (float)(jj[u] & 15u), xi.y + 0.02f, xi.z, xi4.w);   // no LDS
+                    else if (GD_ABL == 42) { const float2 lo = *(const float2 *)((const char *)s_tile + (jj[u] >> 1)); xjv[u] = make_float4(lo.x, lo.y, xi.z + 0.01f, xi4.w); }   // 8-byte entries: LDS side only
                     else xjv[u] = !TILED ? rpos[jj[u]] : S16 ? *(const float4 *)((const char *)s_tile + jj[u]) : s_tile[jj[u]];
                 }
 #pragma unroll

@@ -161,12 +161,33 @@ def main():
     ap.add_argument("--skin", type=float, default=0.0)
     ap.add_argument("--interval", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on the GPU node; gloo for rehearsals")
+    ap.add_argument("--lib", default="", help="developer builds: another HIP library of csrc/ (e.g. libgdyn_dev.so) instead of the product")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --dist-backend gloo)")
+    ap.add_argument("--launch-dry-run", action="store_true", help="with --gpus N > 1 and no launcher: print the launch command and exit")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher (`python bench.py --gpus N`): this process becomes the parent of N fresh rank processes
+        # (one per GPU, torch.distributed.run) and never touches the GPU itself -- nothing before this point imports torch
+        # or loads the HIP library.  Rank 0's JSON line reaches stdout through the inherited descriptor; the parent returns
+        # the launcher's status.  (The reference's ensemble shape: one process per seed, 5-sim-genome/scripts/run_simulation:8-25.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [x for x in sys.argv[1:] if x != "--launch-dry-run"]
+        if a.launch_dry_run:
+            print(json.dumps({"launch": cmd, "torch_imported": "torch" in sys.modules}))
+            return 0
+        return subprocess.run(cmd).returncode
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     import torch
     import torch.distributed as dist
     dev_index = 0 if a.single_device else local_rank
@@ -177,11 +198,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(a.dist_backend)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
     g = importlib.import_module(PKG)
     wl = importlib.import_module(PKG + ".workloads")
     farm = importlib.import_module(PKG + ".farm")
-    hip = g.load()   # fails loudly if the HIP extension is missing
+    hip = g.load(a.lib or None)   # fails loudly if the HIP extension is missing
 
     R, N = a.replicas, a.beads
     # rank 0 generates the model inputs; broadcast to the farm (configs[4]); every rank then owns R
@@ -269,7 +291,8 @@ def main():
         out = {
             "metric": "bead-steps/sec on 100kb whole-genome model, 1 GPU and 8-GPU replica farm",
             "value": N * R * world * a.steps / el, "unit": "bead-steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": world if (world > 1 and a.dist_backend == "nccl") else 0, "dist_backend": a.dist_backend if world > 1 else None,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S-genome-{round(N / 1000)}k (5-sim-genome interphase force field, wall dynamics + scale updates on)",
                        "n_beads": N, "replicas_per_gpu": R, "global_replicas": R * world, "parallelism": f"replica-farm x{world}",
@@ -305,4 +328,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -119,3 +119,39 @@ def test_bench_farm_rehearsal_two_ranks_one_gpu(hip):
     assert line["value"] > 0 and line["steps"] == 40 and line["warmup"] == 10
     assert len(line["config"]["mean_energy_per_bead"]) == 2          # one summary row gathered from each rank
     assert line["config"]["mean_energy_per_bead"][0] != line["config"]["mean_energy_per_bead"][1]      # independent trajectories
+
+
+def test_bench_self_launch_builds_the_rank_command_without_touching_torch():
+    """`python bench.py --gpus N` without a launcher: the parent only starts N rank processes (torch.distributed.run) and
+    must not have imported torch (nothing may initialise the GPU before the ranks exist)."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--launch-dry-run"],
+                         capture_output=True, text=True, timeout=120,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["torch_imported"] is False
+    cmd = d["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:] == ["--gpus", "4", "--steps", "7"]
+
+
+def test_bench_rejects_a_world_size_other_than_gpus():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                         timeout=120, env=dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "--gpus 2" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_without_a_launcher_starts_its_own_ranks(hip):
+    """The way the driver runs the 1-GPU line, with --gpus 2: bench.py itself starts the two ranks (fresh child processes;
+    both on GPU 0 here, gloo standing in for RCCL) and relays rank 0's line."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--single-device",
+                          "--beads", "3000", "--replicas", "8", "--equil", "200", "--steps", "40", "--warmup", "10", "--no-extra",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0
+    assert line["config"]["global_replicas"] == 16 and line["value"] > 0

@@ -1,3 +1,4 @@
+import os
 """Throughput of the other BASELINE.json configurations (informational lines for DESIGN.md)."""
 import importlib, json, os, sys, time
 import numpy as np
@@ -5,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 g = importlib.import_module("2022a-genome-dynamics_amd")
 wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
-hip = g.load()
+hip = g.load(os.environ.get("GDYN_LIB"))      # developer tools only: GDYN_LIB=libgdyn_dev.so / libgdyn_ablN.so
 which = sys.argv[1]
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000

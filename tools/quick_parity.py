@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 g = importlib.import_module("2022a-genome-dynamics_amd")
 wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
-hip = g.load()
+hip = g.load(os.environ.get("GDYN_LIB"))      # developer tools only: GDYN_LIB=libgdyn_dev.so / libgdyn_ablN.so
 orc = g.Lib(os.path.join(ROOT, "oracle", "liboracle.so"))
 
 def cmp(name, a, b):

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 g = importlib.import_module("2022a-genome-dynamics_amd")
 wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
-hip = g.load()
+hip = g.load(os.environ.get("GDYN_LIB"))      # developer tools only: GDYN_LIB=libgdyn_dev.so / libgdyn_ablN.so
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
 s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)

@@ -1,3 +1,4 @@
+import os
 """Experiment: H handles of R replicas each on ONE GPU, stepped concurrently from H host threads (one HIP stream per handle):
 does the overlap of one handle's list builds / launch tails with another handle's steps raise the aggregate throughput?
 usage: two_handles.py [H] [R per handle] [steps]"""
@@ -7,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 g = importlib.import_module("2022a-genome-dynamics_amd")
 wl = importlib.import_module("2022a-genome-dynamics_amd.workloads")
-hip = g.load()
+hip = g.load(os.environ.get("GDYN_LIB"))      # developer tools only: GDYN_LIB=libgdyn_dev.so / libgdyn_ablN.so
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
