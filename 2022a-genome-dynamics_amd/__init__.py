@@ -24,7 +24,7 @@ LIBGDYN_PATH = os.path.join(_HERE, "csrc", "libgdyn.so")      # the product libr
 GD_BOX_OPEN, GD_BOX_PERIODIC = 0, 1
 POT_HARMONIC, POT_SPRING, POT_SEMISPRING, POT_SOFTCORE = 0, 1, 2, 3
 NOISE_PHILOX, NOISE_ZERO, NOISE_HOST, NOISE_MT19937 = 0, 1, 2, 3
-RUN_UPDATE_SCALES, RUN_WALL_DYNAMICS = 1, 2
+RUN_UPDATE_SCALES, RUN_WALL_DYNAMICS, RUN_DEFER_CALLBACK = 1, 2, 4
 TERM_PAIR, TERM_BOND, TERM_BEND, TERM_POINT, TERM_WALL, TERM_DYNAMIC, TERM_ALL = 1, 2, 4, 8, 16, 32, 63
 
 _STATUS = {1: "GD_EINVAL", 2: "GD_ENODEVICE", 3: "GD_EHIP", 4: "GD_ENOMEM", 5: "GD_ESTATE", 6: "GD_EUNSUPPORTED"}
@@ -65,7 +65,8 @@ class Context(C.Structure):
     _fields_ = [("step", C.c_int64), ("time", C.c_double), ("bead_scale", C.c_double), ("bond_scale", C.c_double),
                 ("semiaxes", C.c_double * 3), ("axial_reaction", C.c_double * 3),
                 ("list_entries", C.c_uint64), ("rebuilds", C.c_uint64), ("rollbacks", C.c_uint64),
-                ("rebuild_interval", C.c_uint32), ("list_radius", C.c_double), ("list_path", C.c_uint32)]
+                ("rebuild_interval", C.c_uint32), ("list_radius", C.c_double), ("list_path", C.c_uint32),
+                ("callback_pending", C.c_uint32)]
 
 
 class _RunDesc(C.Structure):
@@ -97,7 +98,7 @@ ABI_SYMBOLS = [
     "gd_get_positions_f32", "gd_set_bead_params", "gd_set_pair_softcore", "gd_add_bond_range",
     "gd_add_bond_pairs", "gd_set_dynamic_pairs", "gd_add_bending_range", "gd_add_point_source",
     "gd_set_ellipsoid_wall", "gd_set_inner_sphere_wall", "gd_set_pair_softwell", "gd_set_scaling", "gd_get_context", "gd_begin_phase", "gd_set_context",
-    "gd_run", "gd_compute_energy", "gd_compute_forces", "gd_search_pairs", "gd_set_tuning",
+    "gd_run", "gd_apply_callback", "gd_compute_energy", "gd_compute_forces", "gd_search_pairs", "gd_set_tuning",
     "gd_get_timing", "gd_get_stream",
 ]
 
@@ -145,6 +146,7 @@ class Lib:
         d.gd_begin_phase.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         d.gd_set_context.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_double)]
         d.gd_run.argtypes = [C.c_void_p, C.POINTER(_RunDesc)]
+        d.gd_apply_callback.argtypes = [C.c_void_p]
         d.gd_compute_energy.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
         d.gd_compute_forces.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
         d.gd_search_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.c_uint64,
@@ -327,6 +329,10 @@ class System:
                       None if rs is None else rs.ctypes.data_as(C.POINTER(C.c_uint64)))
         self.lib.check(self.lib.dll.gd_run(self._h, C.byref(rd)))
         return self.timing()
+
+    def apply_callback(self):
+        """Apply the state updates a run with RUN_DEFER_CALLBACK left pending (no-op otherwise)."""
+        self.lib.check(self.lib.dll.gd_apply_callback(self._h))
 
     # -- observation ----------------------------------------------------------
     def energy(self, terms=TERM_ALL):

@@ -146,6 +146,7 @@ struct gd_system {
     float rn = 0;                   // near-class radius of the tiled list in use
     double a2_ema = 0;              // running mean of (largest displacement)^2 per step of an interval (interval adaptation; 0: none yet)
     double last_dt = 0, last_kT = -1;
+    double pend_dt = 0; int pend_flags = 0;      // timestep and flags of the run that left its last callback pending (GD_RUN_DEFER_CALLBACK)
     double near_frac = 0.65;        // near-class radius = cutoff + near_frac x (list radius - cutoff)
     // gd_search_pairs: device output, counters, and the cached result of the last call
     DevBuf<uint2> sp_out; DevBuf<unsigned long long> sp_count; std::vector<uint2> sp_host;
@@ -476,6 +477,7 @@ extern "C" int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     o->list_entries = s->lcount[r]; o->rebuilds = s->rebuilds; o->rollbacks = s->rollbacks;
     o->rebuild_interval = s->K; o->list_radius = s->rv;
     o->list_path = !s->list_valid && s->rebuilds == 0 ? 0u : (s->list_tiled ? 2u : 1u);
+    o->callback_pending = c.pending ? 1u : 0u;
     return GD_OK;
 }
 
@@ -866,6 +868,39 @@ static hipEvent_t get_event(gd_system *s, size_t i)
     return s->events[i];
 }
 
+// The state updates a GD_RUN_DEFER_CALLBACK run left pending: one k_ctx launch with that run's timestep and flags (the wall-reaction
+// partials of its last step are still the current ones), then the host mirror.
+static int apply_pending(gd_system *s)
+{
+    bool any = false;
+    for (auto &c : s->hctx) any |= c.pending != 0;
+    if (!any) return GD_OK;
+    HIPCHK(hipSetDevice(s->device));
+    GDCHK(upload_ctx(s));
+    StepParams p;
+    fill_common(s, p);
+    p.dt_d = s->pend_dt; p.dt = (float)s->pend_dt; p.run_flags = s->pend_flags;
+    bool common = s->has_scaling && (s->pend_flags & GD_RUN_UPDATE_SCALES);
+    for (uint32_t r = 1; r < s->R && common; r++) common = s->hctx[r].step == s->hctx[0].step && s->hctx[r].pending == s->hctx[0].pending;
+    if (common) {      // same libm exp as a callback applied inside gd_run (see host_scales there)
+        const double time = (double)(s->hctx[0].step + 1) * s->pend_dt;
+        p.scaling.from_host = 1;
+        p.scaling.bead_next = scale_at(s, s->bs_init, s->bs_tau, time);
+        p.scaling.bond_next = scale_at(s, s->bo_init, s->bo_tau, time);
+    }
+    gd_launch_finalize(p, 0, s->stream);
+    s->ccur ^= 1;
+    GDCHK(download_ctx(s));
+    s->state_serial++;
+    return GD_OK;
+}
+
+extern "C" int gd_apply_callback(gd_system *s)
+{
+    if (!s) return fail(GD_EINVAL, "gd_apply_callback: NULL system");
+    return apply_pending(s);
+}
+
 extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
 {
     if (!s || !run) return fail(GD_EINVAL, "gd_run: NULL argument");
@@ -877,6 +912,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     if ((run->flags & GD_RUN_WALL_DYNAMICS) && !s->has_wall) return fail(GD_ESTATE, "gd_run: wall dynamics requested without a wall");
     if ((run->flags & GD_RUN_UPDATE_SCALES) && !s->has_scaling) return fail(GD_ESTATE, "gd_run: scale updates requested without gd_set_scaling");
     GDCHK(prepare(s));
+    GDCHK(apply_pending(s));
     s->state_serial++;
     if (run->timestep != s->last_dt || run->temperature != s->last_kT) { s->a2_ema = 0; s->last_dt = run->timestep; s->last_kT = run->temperature; }   // another regime: measure afresh
     const bool with_list = pair_cutoff(s) > 0;
@@ -961,12 +997,16 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             s->steps_since_build += (uint32_t)n;
             k += n;
         }
-        // apply the callback of the last step, then check the chunk
-        fill_common(s, p);
-        p.dt_d = run->timestep; p.dt = (float)run->timestep; p.run_flags = run->flags;
-        host_scales(p, chunk);
-        gd_launch_finalize(p, 0, s->stream);
-        s->ccur ^= 1;
+        // apply the callback of the last step (unless the caller wants to observe the state its callback sees first), then
+        // check the chunk
+        const bool defer = (run->flags & GD_RUN_DEFER_CALLBACK) && done + chunk == run->steps;
+        if (!defer) {
+            fill_common(s, p);
+            p.dt_d = run->timestep; p.dt = (float)run->timestep; p.run_flags = run->flags;
+            host_scales(p, chunk);
+            gd_launch_finalize(p, 0, s->stream);
+            s->ccur ^= 1;
+        } else { s->pend_dt = run->timestep; s->pend_flags = run->flags; }
         hipEvent_t ev_end = get_event(s, nev++);
         HIPCHK(hipEventRecord(ev_end, s->stream));
         // one round trip for everything the host wants from the chunk: flags, contexts, list counts
@@ -1078,6 +1118,7 @@ extern "C" int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
 {
     if (!s || !forces) return fail(GD_EINVAL, "gd_compute_forces: NULL argument");
     GDCHK(prepare(s));
+    GDCHK(apply_pending(s));      // a force evaluation replaces the wall-reaction partials: the pending callback consumes its own first
     GDCHK(ensure_fresh_list(s));
     StepParams p;
     fill_common(s, p);

@@ -397,7 +397,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         // the record is consumed HERE (an empty asm the compiler has to wait in front of), while it is still the only
         // vector load in flight: placed behind the DMAs, its wait would be a wait for the whole tile.  Its latency
         // overlaps the scalar descriptor loads above.
+#if GD_ABL != 45
         asm volatile("" : "+v"(mo.x), "+v"(mo.y));
+#endif
         GD_STAMP(9);      // record + descriptor arrived
         if (GD_ABL != 12 && (GD_ABL != 33 || (blk & 3u) == 0)) {
             // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
@@ -455,10 +457,14 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     // and the per-bead loads are in flight (the step index comes from a uniform scalar load).  Tiled path: whether the
     // thread owns a bead is not known yet (that is in the build-position record); threads without one have bead id 0.
     float3 z = make_float3(0.f, 0.f, 0.f);
-    if (MODE == GD_MODE_STEP && GD_ABL != 14 && (TILED ? oid != GD_REC_NOBEAD : valid) && p.kT > 0.f) {
+    if (MODE == GD_MODE_STEP && GD_ABL != 14 && (GD_ABL == 45 || (TILED ? oid != GD_REC_NOBEAD : valid)) && p.kT > 0.f) {
         if (p.noise_mode == NOISE_PHILOX) {
             const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
+#if GD_ABL == 45      // timing only: the noise does not wait for the record (upper bound of taking the record load off the critical path)
+            z = philox_normal3(p.seed, (unsigned)gt, step_now + 1, r);
+#else
             z = p.seeds ? philox_normal3(p.seeds[r], oid, step_now + 1, 0u) : philox_normal3(p.seed, oid, step_now + 1, r);
+#endif
         } else if (p.noise_mode == NOISE_HOST) {
             const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
             z = make_float3(h[0], h[1], h[2]);
@@ -1621,10 +1627,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // pad both classes to whole chunks with the bead itself: zero displacement, zero force
             unsigned self = slot;
             if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = S16 ? idx << 4 : idx; }
-            const unsigned needw = ((cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u)) + ((cntB + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u));
-            if ((needw > p.W || (TILED && needw > GD_TILED_MAX_W)) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
+            const unsigned needA = (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u), needB = (cntB + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
+            const unsigned needw = needA + needB;
+            // the tiled record counts the chunks of EACH class in 5 bits: a class beyond 31 chunks does not fit it even when the
+            // row is wide enough for the sum -- flagged like a row overflow, with a need beyond every tiled width (the host
+            // then builds generic lists until the dense transient has passed)
+            const bool class_over = TILED && (needA > 31u * GD_UNROLL || needB > 31u * GD_UNROLL);
+            if ((needw > p.W || (TILED && needw > GD_TILED_MAX_W) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
                 p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
-                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], needw);
+                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], class_over ? max(needw, GD_TILED_MAX_W + 1u) : needw);
             }
             listlen = min(found, p.W);
             while (cnt % GD_UNROLL) push(self);

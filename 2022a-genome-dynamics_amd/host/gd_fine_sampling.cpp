@@ -113,14 +113,15 @@ private:
         while (step < _config.interphase_steps) {
             long const next = std::min<long>(_config.interphase_steps, std::min(next_multiple(step, _config.interphase_logging_interval),
                                                                                 next_multiple(step, _config.interphase_sampling_interval)));
-            // stop one step early: callback(next) logs the semiaxes left by callback(next-1)
-            if (next - step > 1) { run.steps = next - step - 1; chk(gd_run(_sys, &run)); }
+            // callback(next) computes the energy, logs and saves on the semiaxes callback(next - 1) left, THEN moves the wall
+            // (simulation_driver_interphase.cc:19-33): the last callback of the chunk stays pending over the observation
+            run.steps = next - step; run.flags = GD_RUN_WALL_DYNAMICS | GD_RUN_DEFER_CALLBACK; chk(gd_run(_sys, &run));
             gd_context ctx;
             chk(gd_get_context(_sys, 0, &ctx));
             std::copy(ctx.semiaxes, ctx.semiaxes + 3, _context.wall_semiaxes);
-            run.steps = 1; chk(gd_run(_sys, &run));
             step = next;
             observe(step);
+            chk(gd_apply_callback(_sys));
         }
     }
 

@@ -2,6 +2,11 @@
 // reference creates its input files with Python/h5py, 5-sim-genome/src/prepare, which is not available here).
 //   gd_h5tool make-input <out.h5> <config.json> <chroms.tsv> <ab.f64> <positions.f64> [<nucleolus_bonds.u32> [<nucleolus_ranges.u32>]]
 //        chroms.tsv rows: name start end centromere_start centromere_end; raw little-endian arrays (N,2)/(N,3)
+//   gd_h5tool make-metadata <out.h5> <dir>             the file `prepare` creates (5-sim-genome/src/prepare/run.py:21-123) from raw tables in <dir>:
+//        config.json, ab.f32 (N,2), types.i8 (N), chromosomes.tsv (name start end cen_start cen_end), nucleoli.tsv (name start end),
+//        nucleolus_bonds.i32 (M,2)
+//   gd_h5tool dump-metadata <file> <dir>               the same tables back out of a file (+ enum.tsv, keys_*.json)
+//   gd_h5tool put-positions-f64 <file> <phase> <step> <in.f64>   replaces the snapshot with a float64 positions dataset (refine/run.py:41-46)
 //   gd_h5tool steps <file> <phase>                     numerically ordered step list
 //   gd_h5tool positions <file> <phase> <step> <out.f64>
 //   gd_h5tool context <file> <phase> <step>            prints the JSON context fields
@@ -61,6 +66,76 @@ int main(int argc, char **argv)
             store.save_metadata(std::string(cfg.begin(), cfg.end()), abv, chroms, nranges, bonds);
             store.set_phase("relaxation");
             store.save_positions(0, reinterpret_cast<double const *>(posraw.data()), n);
+            return 0;
+        }
+        if (cmd == "make-metadata" && argc == 4) {
+            std::string const dir = std::string(argv[3]) + "/";
+            auto const cfg = slurp(dir + "config.json"), abraw = slurp(dir + "ab.f32"), tyraw = slurp(dir + "types.i8"), nbraw = slurp(dir + "nucleolus_bonds.i32");
+            std::size_t const n = tyraw.size();
+            if (abraw.size() != n * 2 * sizeof(float)) throw std::runtime_error("ab.f32 and types.i8 disagree on N");
+            auto const *ab = reinterpret_cast<float const *>(abraw.data());
+            std::vector<gd::ab_factor> abv(n);
+            for (std::size_t i = 0; i < n; i++) abv[i] = {ab[2 * i], ab[2 * i + 1]};
+            std::vector<std::int8_t> types(tyraw.begin(), tyraw.end());
+            std::vector<gd::chromosome_range> chroms;
+            std::ifstream tsv(dir + "chromosomes.tsv");
+            for (std::string line; std::getline(tsv, line);) {
+                std::istringstream ss(line);
+                gd::chromosome_range c;
+                if (ss >> c.name >> c.start >> c.end >> c.centromere_start >> c.centromere_end) chroms.push_back(c);
+            }
+            std::vector<gd::index_range> nranges;
+            std::vector<std::string> nnames;
+            std::ifstream ntsv(dir + "nucleoli.tsv");
+            for (std::string line; std::getline(ntsv, line);) {
+                std::istringstream ss(line);
+                std::string name; gd::index_range r;
+                if (ss >> name >> r.begin >> r.end) { nnames.push_back(name); nranges.push_back(r); }
+            }
+            std::vector<gd::nucleolus_bond> bonds;
+            auto const *nb = reinterpret_cast<std::int32_t const *>(nbraw.data());
+            for (std::size_t k = 0; k + 1 < nbraw.size() / sizeof(std::int32_t); k += 2) bonds.push_back({(std::size_t)nb[k], (std::size_t)nb[k + 1]});
+            gd::trajectory_store store(argv[2], /*create=*/true);
+            store.save_metadata(std::string(cfg.begin(), cfg.end()), abv, chroms, nranges, bonds, &types, &nnames);
+            store.create_phase_groups();
+            return 0;
+        }
+        if (cmd == "dump-metadata" && argc == 4) {
+            std::string const dir = std::string(argv[3]) + "/";
+            gd::trajectory_store store(argv[2]);
+            auto put = [&](std::string const &name, void const *data, std::size_t bytes) {
+                std::ofstream out(dir + name, std::ios::binary);
+                out.write(static_cast<char const *>(data), (std::streamsize)bytes);
+            };
+            auto const cfg = store.load_config_text();
+            put("config.json", cfg.data(), cfg.size());
+            std::vector<float> ab;
+            for (auto const &f : store.load_particle_data()) { ab.push_back((float)f.a); ab.push_back((float)f.b); }
+            put("ab.f32", ab.data(), ab.size() * sizeof(float));
+            std::vector<std::pair<std::string, int>> members;
+            auto const types = store.load_particle_types(&members);
+            put("types.i8", types.data(), types.size());
+            std::ofstream en(dir + "enum.tsv");
+            for (auto const &m : members) en << m.first << ' ' << m.second << '\n';
+            std::ofstream ch(dir + "chromosomes.tsv");
+            for (auto const &c : store.load_chromosomes()) ch << c.name << ' ' << c.start << ' ' << c.end << ' ' << c.centromere_start << ' ' << c.centromere_end << '\n';
+            std::vector<std::int32_t> nr, nb;
+            for (auto const &r : store.load_nucleolus_ranges()) { nr.push_back((std::int32_t)r.begin); nr.push_back((std::int32_t)r.end); }
+            for (auto const &b : store.load_nucleolus_bonds()) { nb.push_back((std::int32_t)b.nor_index); nb.push_back((std::int32_t)b.nuc_index); }
+            put("nucleolus_ranges.i32", nr.data(), nr.size() * sizeof(std::int32_t));
+            put("nucleolus_bonds.i32", nb.data(), nb.size() * sizeof(std::int32_t));
+            for (char const *ds : {"chromosome_ranges", "centromere_ranges", "nucleolus_ranges"}) {
+                auto const keys = store.load_keys(ds);
+                put(std::string("keys_") + ds + ".json", keys.data(), keys.size());
+            }
+            return 0;
+        }
+        if (cmd == "put-positions-f64" && argc == 6) {
+            auto const raw = slurp(argv[5]);
+            if (raw.size() % (3 * sizeof(double))) throw std::runtime_error("positions file is not (N,3) float64");
+            gd::trajectory_store store(argv[2]);
+            store.set_phase(argv[3]);
+            store.replace_positions_f64(std::stol(argv[4]), reinterpret_cast<double const *>(raw.data()), raw.size() / (3 * sizeof(double)));
             return 0;
         }
         if (cmd == "steps" && argc == 4) {
@@ -129,7 +204,7 @@ int main(int argc, char **argv)
             else for (auto const &s : gd::h5::read_string_list(loc, name)) std::cout << s << '\n';
             return 0;
         }
-        std::cerr << "usage: gd_h5tool make-input|steps|positions|context|contacts|dataset|strings ...\n";
+        std::cerr << "usage: gd_h5tool make-input|make-metadata|dump-metadata|put-positions-f64|steps|positions|context|contacts|dataset|strings ...\n";
         return 1;
     } catch (std::exception const &e) {
         std::cerr << "error: " << e.what() << '\n';

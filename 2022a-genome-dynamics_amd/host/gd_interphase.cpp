@@ -80,9 +80,8 @@ public:
         set_default(_config.b_core_bond_length, _config.chromatin_bond_length);
         for (std::size_t r = 0; r < _R; r++) {
             auto const cfg = gd::parse_simulation_config(_stores[r]->load_config_text());
-            if (r > 0 && (cfg.interphase_steps != _config.interphase_steps || cfg.relaxation_steps != _config.relaxation_steps ||
-                          cfg.interphase_timestep != _config.interphase_timestep || cfg.interphase_sampling_interval != _config.interphase_sampling_interval ||
-                          cfg.a_core_diameter != _config.a_core_diameter || cfg.wall_mobility != _config.wall_mobility))
+            // one handle runs one force field and one schedule: every config entry except the seeds must agree
+            if (r > 0 && !gd::same_model_config(_stores[r]->load_config_text(), _stores[0]->load_config_text()))
                 throw std::runtime_error("batched trajectories must share one simulation config (seeds aside)");
             _random.emplace_back(cfg.interphase_seed);          // 1st draw: relaxation seed, 2nd: interphase seed
         }
@@ -101,6 +100,17 @@ private:
             if (pr.size() != p0.size()) throw std::runtime_error("batched trajectories must hold the same model (bead count differs)");
             for (std::size_t i = 0; i < p0.size(); i++)
                 if (pr[i].a != p0[i].a || pr[i].b != p0[i].b) throw std::runtime_error("batched trajectories must hold the same model (A/B factors differ)");
+            // the topology the handle is built from is file 0's: chains, nucleolar ranges and bonds must agree as well
+            auto const c0 = _stores[0]->load_chromosomes(), cr = _stores[r]->load_chromosomes();
+            bool same = c0.size() == cr.size();
+            for (std::size_t i = 0; same && i < c0.size(); i++) same = c0[i].start == cr[i].start && c0[i].end == cr[i].end;
+            auto const n0 = _stores[0]->load_nucleolus_ranges(), nr = _stores[r]->load_nucleolus_ranges();
+            same = same && n0.size() == nr.size();
+            for (std::size_t i = 0; same && i < n0.size(); i++) same = n0[i].begin == nr[i].begin && n0[i].end == nr[i].end;
+            auto const b0 = _stores[0]->load_nucleolus_bonds(), br = _stores[r]->load_nucleolus_bonds();
+            same = same && b0.size() == br.size();
+            for (std::size_t i = 0; same && i < b0.size(); i++) same = b0[i].nor_index == br[i].nor_index && b0[i].nuc_index == br[i].nuc_index;
+            if (!same) throw std::runtime_error("batched trajectories must hold the same model (chromosome / nucleolus tables differ)");
         }
         // setup_context (simulation_driver.cc:43-51)
         gd::context c{};
@@ -148,18 +158,21 @@ private:
         }
     }
 
-    // advance to `target`, stopping one step early to capture the context the reference's callback(target) sees:
-    // its log/snapshot use the scales and semiaxes left by callback(target-1) (they are updated at the END of a callback)
+    // advance to `target` and leave the state updates of callback(target) pending (GD_RUN_DEFER_CALLBACK): what the host
+    // part of the reference's callback(target) sees -- mean_energy, the log line, the saved context and the contact search all
+    // run BEFORE update_bead_scale() / update_wall_semiaxes() (simulation_driver_interphase.cc:20-43), i.e. on the scales, the
+    // semiaxes and the contact distance that callback(target - 1) left
     void advance(gd_run_desc &run, long &step, long target)
     {
-        if (target - step > 1) { run.steps = target - step - 1; chk(gd_run(_sys, &run)); }
+        run.steps = target - step; run.flags |= GD_RUN_DEFER_CALLBACK;
+        chk(gd_run(_sys, &run));
         for (std::size_t r = 0; r < _R; r++) {
             gd_context ctx;
             chk(gd_get_context(_sys, (uint32_t)r, &ctx));
             _context[r].bead_scale = ctx.bead_scale; _context[r].bond_scale = ctx.bond_scale;
             std::copy(ctx.semiaxes, ctx.semiaxes + 3, _context[r].wall_semiaxes);
+            _contacts[r].set_contact_distance(_config.contactmap_distance * ctx.bead_scale);     // set by update_bead_scale() of callback(target - 1), :66
         }
-        if (target > step) { run.steps = 1; chk(gd_run(_sys, &run)); }
         step = target;
     }
 
@@ -252,12 +265,7 @@ private:
                                                        next_multiple(step, _config.contactmap_update_interval)}));
             advance(run, step, next);
             observe(step);
-            // the contact distance for later updates is the one set at the end of this callback
-            for (std::size_t r = 0; r < _R; r++) {
-                gd_context ctx;
-                chk(gd_get_context(_sys, (uint32_t)r, &ctx));
-                _contacts[r].set_contact_distance(_config.contactmap_distance * ctx.bead_scale);
-            }
+            chk(gd_apply_callback(_sys));      // update_bead_scale() + update_wall_semiaxes() of callback(step), on the device
         }
     }
 

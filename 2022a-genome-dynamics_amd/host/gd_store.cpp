@@ -92,15 +92,8 @@ std::vector<nucleolus_bond> trajectory_store::load_nucleolus_bonds()
     return out;
 }
 
-static void write_ranges(hid_t group, std::string const &name, std::vector<chromosome_range> const &chroms)
+static void write_keys(hid_t ds, nlohmann::json const &keys)
 {
-    std::vector<int> ranges;
-    nlohmann::json keys;
-    for (auto const &c : chroms) {
-        keys[c.name] = ranges.size() / 2;
-        ranges.push_back((int)c.start); ranges.push_back((int)c.end);
-    }
-    hid ds(write_array<int>(group, name, ranges.data(), chroms.size(), 2, H5T_NATIVE_INT, H5T_STD_I32LE));
     hid type(vlen_string_type()), space(H5Screate(H5S_SCALAR));
     hid attr(H5Acreate2(ds, "keys", type, space, H5P_DEFAULT, H5P_DEFAULT));
     std::string const text = keys.dump();
@@ -108,22 +101,112 @@ static void write_ranges(hid_t group, std::string const &name, std::vector<chrom
     check(H5Awrite(attr, type, &p) >= 0, "cannot write keys attribute");
 }
 
+static void write_ranges(hid_t group, std::string const &name, std::vector<chromosome_range> const &chroms)
+{
+    std::vector<int> ranges;
+    nlohmann::json keys = nlohmann::json::object();
+    for (auto const &c : chroms) {
+        keys[c.name] = ranges.size() / 2;
+        ranges.push_back((int)c.start); ranges.push_back((int)c.end);
+    }
+    hid ds(write_array<int>(group, name, ranges.data(), chroms.size(), 2, H5T_NATIVE_INT, H5T_STD_I32LE));
+    write_keys(ds, keys);
+}
+
+// particle type codes and their descriptive names (prepare/system_definition.py:5-24; the enum of /metadata/particle_types)
+static std::pair<char const *, int> const particle_type_names[] = {
+    {"active_NOR", 5}, {"silent_NOR", 6}, {"centromere", 4}, {"A", 1}, {"B", 2}, {"u", 3}, {"nucleolus", 7}};
+
 void trajectory_store::save_metadata(std::string const &config_json, std::vector<ab_factor> const &ab, std::vector<chromosome_range> const &chroms,
-                                     std::vector<index_range> const &nranges, std::vector<nucleolus_bond> const &bonds)
+                                     std::vector<index_range> const &nranges, std::vector<nucleolus_bond> const &bonds,
+                                     std::vector<std::int8_t> const *types, std::vector<std::string> const *nucleolus_names)
 {
     hid meta(require_group(_file, "metadata"));
     write_string(meta, "config", config_json);
     std::vector<float> abv;
     for (auto const &f : ab) { abv.push_back((float)f.a); abv.push_back((float)f.b); }
     hid(write_array<float>(meta, "ab_factors", abv.data(), ab.size(), 2, H5T_NATIVE_FLOAT, H5T_IEEE_F32LE));
+    if (types) {
+        check(types->size() == ab.size(), "particle_types and ab_factors differ in length");
+        unlink_if_present(meta, "particle_types");
+        hid etype(H5Tenum_create(H5T_STD_I8LE));
+        for (auto const &m : particle_type_names) { std::int8_t v = (std::int8_t)m.second; H5Tenum_insert(etype, m.first, &v); }
+        hsize_t n = types->size();
+        hid space(H5Screate_simple(1, &n, nullptr));
+        hid ds(H5Dcreate2(meta, "particle_types", etype, space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT));
+        check(ds >= 0, "cannot create particle_types");
+        if (n) check(H5Dwrite(ds, etype, H5S_ALL, H5S_ALL, H5P_DEFAULT, types->data()) >= 0, "cannot write particle_types");
+    }
     write_ranges(meta, "chromosome_ranges", chroms);
     std::vector<int> cen, nr, nb;
-    for (auto const &c : chroms) { cen.push_back((int)c.centromere_start); cen.push_back((int)c.centromere_end); }
-    for (auto const &r : nranges) { nr.push_back((int)r.begin); nr.push_back((int)r.end); }
+    nlohmann::json chrom_keys = nlohmann::json::object(), nuc_keys = nlohmann::json::object();
+    for (auto const &c : chroms) { chrom_keys[c.name] = cen.size() / 2; cen.push_back((int)c.centromere_start); cen.push_back((int)c.centromere_end); }
+    for (std::size_t k = 0; k < nranges.size(); k++) {
+        if (nucleolus_names) nuc_keys[nucleolus_names->at(k)] = k;
+        nr.push_back((int)nranges[k].begin); nr.push_back((int)nranges[k].end);
+    }
     for (auto const &b : bonds) { nb.push_back((int)b.nor_index); nb.push_back((int)b.nuc_index); }
-    hid(write_array<int>(meta, "centromere_ranges", cen.data(), chroms.size(), 2, H5T_NATIVE_INT, H5T_STD_I32LE));
-    hid(write_array<int>(meta, "nucleolus_ranges", nr.data(), nranges.size(), 2, H5T_NATIVE_INT, H5T_STD_I32LE));
+    {
+        hid ds(write_array<int>(meta, "centromere_ranges", cen.data(), chroms.size(), 2, H5T_NATIVE_INT, H5T_STD_I32LE));
+        write_keys(ds, chrom_keys);          // same keys as chromosome_ranges (prepare/run.py:101-108)
+    }
+    {
+        hid ds(write_array<int>(meta, "nucleolus_ranges", nr.data(), nranges.size(), 2, H5T_NATIVE_INT, H5T_STD_I32LE));
+        write_keys(ds, nuc_keys);            // chain name of each span (prepare/run.py:111-118)
+    }
     hid(write_array<int>(meta, "nucleolus_bonds", nb.data(), bonds.size(), 2, H5T_NATIVE_INT, H5T_STD_I32LE));
+    flush();
+}
+
+void trajectory_store::create_phase_groups()
+{
+    hid snaps(require_group(_file, "snapshots"));
+    for (char const *phase : {"spindle", "packing", "relaxation", "interphase"}) hid(require_group(snaps, phase));
+    flush();
+}
+
+std::vector<std::int8_t> trajectory_store::load_particle_types(std::vector<std::pair<std::string, int>> *enum_members)
+{
+    hid meta(H5Gopen2(_file, "metadata", H5P_DEFAULT));
+    hid ds(H5Dopen2(meta, "particle_types", H5P_DEFAULT));
+    check(ds >= 0, "missing dataset particle_types");
+    hid space(H5Dget_space(ds)), ftype(H5Dget_type(ds));
+    std::vector<std::int8_t> out((std::size_t)std::max<hssize_t>(H5Sget_simple_extent_npoints(space), 0));
+    if (!out.empty()) check(H5Dread(ds, H5T_NATIVE_INT8, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.data()) >= 0, "cannot read particle_types");
+    if (enum_members && H5Tget_class(ftype) == H5T_ENUM) {
+        int const nm = H5Tget_nmembers(ftype);
+        for (int k = 0; k < nm; k++) {
+            char *name = H5Tget_member_name(ftype, (unsigned)k);
+            std::int8_t v = 0;
+            H5Tget_member_value(ftype, (unsigned)k, &v);
+            enum_members->push_back({name ? name : "", (int)v});
+            if (name) H5free_memory(name);
+        }
+    }
+    return out;
+}
+
+std::string trajectory_store::load_keys(std::string const &dataset)
+{
+    hid meta(H5Gopen2(_file, "metadata", H5P_DEFAULT));
+    hid ds(H5Dopen2(meta, dataset.c_str(), H5P_DEFAULT));
+    check(ds >= 0, "missing dataset " + dataset);
+    hid attr(H5Aopen(ds, "keys", H5P_DEFAULT));
+    check(attr >= 0, dataset + " has no 'keys' attribute");
+    return read_string_from(attr, true);
+}
+
+void trajectory_store::replace_positions_f64(long step, double const *xyz, std::size_t n)
+{
+    hid snaps(require_group(_file, "snapshots")), phase(require_group(snaps, _phase));
+    unlink_if_present(phase, std::to_string(step));             // `del phase["0"]`
+    hid snap(H5Gcreate2(phase, std::to_string(step).c_str(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT));
+    check(snap >= 0, "cannot create snapshot group");
+    hsize_t dims[2] = {n, 3};
+    hid space(H5Screate_simple(2, dims, nullptr));
+    hid ds(H5Dcreate2(snap, "positions", H5T_IEEE_F64LE, space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT));      // h5py's default: contiguous float64
+    check(ds >= 0, "cannot create positions");
+    if (n) check(H5Dwrite(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, xyz) >= 0, "cannot write positions");
     flush();
 }
 

@@ -54,8 +54,15 @@ public:
     std::vector<ab_factor> load_particle_data();
     std::vector<index_range> load_nucleolus_ranges();
     std::vector<nucleolus_bond> load_nucleolus_bonds();
+    // types: /metadata/particle_types (i8 enum, prepare/run.py:81-88) when given; nucleolus_names: the keys of nucleolus_ranges
     void save_metadata(std::string const &config_json, std::vector<ab_factor> const &ab, std::vector<chromosome_range> const &chroms,
-                       std::vector<index_range> const &nucleolus_ranges, std::vector<nucleolus_bond> const &bonds);
+                       std::vector<index_range> const &nucleolus_ranges, std::vector<nucleolus_bond> const &bonds,
+                       std::vector<std::int8_t> const *types = nullptr, std::vector<std::string> const *nucleolus_names = nullptr);
+    void create_phase_groups();         // /snapshots/{spindle,packing,relaxation,interphase} (prepare/run.py:60-68)
+    std::vector<std::int8_t> load_particle_types(std::vector<std::pair<std::string, int>> *enum_members = nullptr);
+    std::string load_keys(std::string const &dataset);      // the JSON text of /metadata/<dataset>'s "keys" attribute
+    // /snapshots/<phase>/<step>/positions as plain float64 (N,3), replacing the snapshot group (refine/run.py:41-46)
+    void replace_positions_f64(long step, double const *xyz, std::size_t n);
 
     // snapshots
     void set_phase(std::string const &phase) { _phase = phase; }

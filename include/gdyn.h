@@ -217,6 +217,7 @@ typedef struct {
     uint32_t rebuild_interval;
     double   list_radius;
     uint32_t list_path;      /* kernel path of the list in use: 0 none yet, 1 generic (global gather), 2 LDS-tiled */
+    uint32_t callback_pending;   /* 1: the state updates of callback(step + 1) are pending (GD_RUN_DEFER_CALLBACK) */
 } gd_context;
 
 int gd_get_context(gd_system *sys, uint32_t replica, gd_context *out);
@@ -232,7 +233,13 @@ int gd_set_context(gd_system *sys, uint32_t replica, int64_t step,
 enum { GD_NOISE_PHILOX = 0, GD_NOISE_ZERO = 1, GD_NOISE_HOST = 2 };
 enum {
     GD_RUN_UPDATE_SCALES = 1,   /* callback runs update_bead_scale()   (simulation_driver_interphase.cc:42) */
-    GD_RUN_WALL_DYNAMICS = 2    /* callback runs update_wall_semiaxes() (simulation_driver_interphase.cc:43) */
+    GD_RUN_WALL_DYNAMICS = 2,   /* callback runs update_wall_semiaxes() (simulation_driver_interphase.cc:43) */
+    GD_RUN_DEFER_CALLBACK = 4   /* the state updates of the LAST step's callback are left pending when gd_run returns: positions are
+                                   those of step k, the context is the one callback(k-1) left -- what the reference's callback(k)
+                                   sees when it computes mean_energy, prints and saves (simulation_driver_interphase.cc:20-22,
+                                   29-32) BEFORE update_bead_scale() / update_wall_semiaxes() (:42-43).  gd_compute_energy,
+                                   gd_get_context, gd_get_positions*, gd_search_pairs observe that state; the pending updates are
+                                   applied by gd_apply_callback(), by the next gd_run() or by gd_compute_forces() */
 };
 
 /* md::simulate_brownian_dynamics(system, {temperature,timestep,spacestep,steps,seed,callback})
@@ -256,6 +263,9 @@ typedef struct {
 } gd_run_desc;
 
 int gd_run(gd_system *sys, const gd_run_desc *run);
+/* Applies the state updates a GD_RUN_DEFER_CALLBACK run left pending (update_bead_scale / update_wall_semiaxes of its last
+ * callback, simulation_driver_interphase.cc:42-43) with that run's timestep and flags.  No-op when nothing is pending. */
+int gd_apply_callback(gd_system *sys);
 
 /* ------------------------------------------------------------- observation */
 

@@ -45,6 +45,7 @@ typedef struct {
     int64_t step;
     double time, bead_scale, bond_scale;
     double semi[3], react[3];
+    int pending; double pend_dt; int pend_flags;      /* GD_RUN_DEFER_CALLBACK: callback(step + 1) not applied yet */
 } ctx_t;
 
 typedef struct {
@@ -484,7 +485,7 @@ int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     ctx_t *c = &s->ctx[r];
     o->step = c->step; o->time = c->time; o->bead_scale = c->bead_scale; o->bond_scale = c->bond_scale;
     memcpy(o->semiaxes, c->semi, sizeof c->semi); memcpy(o->axial_reaction, c->react, sizeof c->react);
-    o->rebuilds = s->rebuilds;
+    o->rebuilds = s->rebuilds; o->callback_pending = (uint32_t)c->pending;
     if (s->vl_start[r]) { o->list_entries = 2ull * s->vl_start[r][s->N]; o->list_radius = s->vl_rv[r]; }
     return GD_OK;
 }
@@ -494,7 +495,7 @@ int gd_begin_phase(gd_system *s, const double *semi)
     if (!s) return fail(GD_EINVAL, "gd_begin_phase: NULL system");
     for (uint32_t r = 0; r < s->R; r++) {
         ctx_t *c = &s->ctx[r];
-        c->step = 0; c->time = 0;
+        c->step = 0; c->time = 0; c->pending = 0;
         if (s->has_scaling) { c->bead_scale = s->bs_init; c->bond_scale = s->bo_init; }
         if (semi) memcpy(c->semi, semi + 3 * r, sizeof c->semi);
     }
@@ -508,7 +509,7 @@ int gd_set_context(gd_system *s, uint32_t r, int64_t step, double bead_scale, do
     if (r >= s->R) return fail(GD_EINVAL, "gd_set_context: replica out of range");
     if (!(bead_scale > 0) || !(bond_scale > 0)) return fail(GD_EINVAL, "gd_set_context: scales must be positive");
     ctx_t *c = &s->ctx[r];
-    c->step = step; c->bead_scale = bead_scale; c->bond_scale = bond_scale;
+    c->step = step; c->bead_scale = bead_scale; c->bond_scale = bond_scale; c->pending = 0;
     if (semi) memcpy(c->semi, semi, sizeof c->semi);
     free(s->vl_start[r]); s->vl_start[r] = NULL;
     return GD_OK;
@@ -890,9 +891,34 @@ int gd_compute_energy(gd_system *s, uint32_t mask, double *energy)
     return GD_OK;
 }
 
+/* the state updates of callback(gstep): simulation_driver_interphase.cc:14,42-43,59-80 */
+static void run_callback(gd_system *s, ctx_t *c, int64_t gstep, double dt, int flags)
+{
+    c->step = gstep; c->time = (double)gstep * dt;
+    if (flags & GD_RUN_UPDATE_SCALES) {
+        c->bead_scale = 1 - (1 - s->bs_init) * exp(-c->time / s->bs_tau);
+        c->bond_scale = 1 - (1 - s->bo_init) * exp(-c->time / s->bo_tau);
+    }
+    if (flags & GD_RUN_WALL_DYNAMICS)
+        for (int q = 0; q < 3; q++)
+            c->semi[q] += dt * s->wall.mobility * (c->react[q] - s->wall.semiaxes_spring[q] * c->semi[q]);
+    c->pending = 0;
+}
+
+int gd_apply_callback(gd_system *s)
+{
+    if (!s) return fail(GD_EINVAL, "gd_apply_callback: NULL system");
+    for (uint32_t r = 0; r < s->R; r++) {
+        ctx_t *c = &s->ctx[r];
+        if (c->pending) run_callback(s, c, c->step + 1, c->pend_dt, c->pend_flags);
+    }
+    return GD_OK;
+}
+
 int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
 {
     if (!s || !forces) return fail(GD_EINVAL, "gd_compute_forces: NULL argument");
+    gd_apply_callback(s);      /* a force evaluation replaces stats.axial_reaction: the pending callback consumes its own first */
     for (uint32_t r = 0; r < s->R; r++) compute(s, r, mask, forces + (size_t)r * s->N * 3, 0);
     return GD_OK;
 }
@@ -912,6 +938,7 @@ int gd_run(gd_system *s, const gd_run_desc *run)
     if ((run->flags & GD_RUN_UPDATE_SCALES) && !s->has_scaling) return fail(GD_ESTATE, "gd_run: scale updates requested without gd_set_scaling");
     uint32_t N = s->N, R = s->R;
     double dt = run->timestep, kT = run->temperature;
+    gd_apply_callback(s);
     double *F = xcalloc((size_t)N * 3, sizeof(double));
     mt64_t *mt = NULL;
     if (run->noise_mode == GD_NOISE_MT19937) { mt = xcalloc(R, sizeof *mt); for (uint32_t r = 0; r < R; r++) mt64_seed(&mt[r], run->replica_seeds ? run->replica_seeds[r] : run->seed + r); }
@@ -937,14 +964,8 @@ int gd_run(gd_system *s, const gd_run_desc *run)
                 for (int q = 0; q < 3; q++) x[3 * i + q] += mu_dt * F[3 * i + q] + sg * z[q];
             }
             /* callback(gstep): simulation_driver_interphase.cc:12-44 */
-            c->step = gstep; c->time = (double)gstep * dt;
-            if (run->flags & GD_RUN_UPDATE_SCALES) {
-                c->bead_scale = 1 - (1 - s->bs_init) * exp(-c->time / s->bs_tau);
-                c->bond_scale = 1 - (1 - s->bo_init) * exp(-c->time / s->bo_tau);
-            }
-            if (run->flags & GD_RUN_WALL_DYNAMICS)
-                for (int q = 0; q < 3; q++)
-                    c->semi[q] += dt * s->wall.mobility * (c->react[q] - s->wall.semiaxes_spring[q] * c->semi[q]);
+            if ((run->flags & GD_RUN_DEFER_CALLBACK) && k == run->steps) { c->pending = 1; c->pend_dt = dt; c->pend_flags = run->flags; }
+            else run_callback(s, c, gstep, dt, run->flags);
         }
     }
     free(F); free(mt);

@@ -134,7 +134,10 @@ def _python_driver(lib, oracle, cfg, a, b, x0q, ranges, droplet=False):
     ctx = dict(time=0.0, bead_scale=cfg["bead_scale_init"], bond_scale=cfg["bond_scale_init"], semi=semi.copy())
 
     def snap(phase, step):
-        out[(phase, step)] = (s.positions_f32(quantize=True)[0].astype(np.float64), dict(ctx, semi=ctx["semi"].copy()))
+        # mean_energy as the reference's callback computes it: under the context the previous callback left
+        # (simulation_driver_interphase.cc:20-22 comes before :42-43)
+        out[(phase, step)] = (s.positions_f32(quantize=True)[0].astype(np.float64),
+                              dict(ctx, semi=ctx["semi"].copy(), mean_energy=float(s.energy()[0]) / N))
 
     # relaxation
     s.set_positions(x0q)
@@ -161,11 +164,12 @@ def _python_driver(lib, oracle, cfg, a, b, x0q, ranges, droplet=False):
     step = 0
     while step < INTER:
         nxt = min(INTER, (step // 10 + 1) * 10)
-        if nxt - step > 1:
-            s.run(nxt - step - 1, dt, cfg["interphase_temperature"], seed=seed_inter, flags=flags)
+        # callback(nxt): observation on the state callback(nxt - 1) left, then the state updates
+        s.run(nxt - step, dt, cfg["interphase_temperature"], seed=seed_inter, flags=flags | g.RUN_DEFER_CALLBACK)
         c = s.context()
+        assert c.callback_pending == 1 and c.step == nxt - 1
         ctx.update(bead_scale=c.bead_scale, bond_scale=c.bond_scale, semi=np.array(c.semiaxes))
-        s.run(1, dt, cfg["interphase_temperature"], seed=seed_inter, flags=flags)
+        dist = cfg["contactmap_distance"] * c.bead_scale            # set by update_bead_scale() of callback(nxt - 1)
         step = nxt
         ctx["time"] = step * dt
         if step % 20 == 0:
@@ -175,7 +179,8 @@ def _python_driver(lib, oracle, cfg, a, b, x0q, ranges, droplet=False):
         if step % 20 == 0:
             saved_contacts[step] = dict(contacts)
             contacts = {}
-        dist = cfg["contactmap_distance"] * s.context().bead_scale
+        s.apply_callback()
+        assert s.context().callback_pending == 0 and s.context().step == nxt
     return out, saved_contacts
 
 
@@ -199,6 +204,10 @@ def _check_run(tmp, lib, oracle, driver, atol, env=None, droplet=False):
         assert c["time"] == pytest.approx(ctx["time"], abs=1e-15)
         assert c["bead_scale"] == pytest.approx(ctx["bead_scale"], rel=1e-12)
         assert np.allclose(c["wall_semiaxes"], ctx["semi"], rtol=0, atol=max(atol * 1e-3, 1e-12))
+        if atol == 0:
+            assert c["mean_energy"] == ctx["mean_energy"], (phase, step)          # bit-equal: same context, same positions
+        else:
+            assert c["mean_energy"] == pytest.approx(ctx["mean_energy"], rel=1e-4, abs=1e-4)
     for step, cm in ref_contacts.items():
         rows = [tuple(map(int, ln.split())) for ln in _tool("contacts", tmp / "traj.h5", "interphase", step).splitlines()]
         assert rows == sorted(rows)                                      # row-major (i, j) order, i < j
@@ -484,13 +493,12 @@ def _python_fine(lib, oracle, cfg, a, b, ranges, x_restart, ctx_restart):
     step = 0
     while step < FINE_STEPS:
         nxt = min(FINE_STEPS, (step // 100 + 1) * 100)
-        if nxt - step > 1:
-            s.run(nxt - step - 1, dt, 0.0, seed=seed, flags=g.RUN_WALL_DYNAMICS)
-        semi = np.array(s.context().semiaxes)
-        s.run(1, dt, 0.0, seed=seed, flags=g.RUN_WALL_DYNAMICS)
+        s.run(nxt - step, dt, 0.0, seed=seed, flags=g.RUN_WALL_DYNAMICS | g.RUN_DEFER_CALLBACK)
+        semi = np.array(s.context().semiaxes)            # left by callback(nxt - 1); the energy is evaluated with them
         step = nxt
         if step % 100 == 0:
             out[step] = (s.positions_f32(quantize=True)[0].astype(np.float64), semi.copy(), float(s.energy()[0]) / N)
+        s.apply_callback()
     assert s.context().bead_scale == 1.0 and s.context().bond_scale == 1.0
     s.close()
     return out
@@ -516,7 +524,10 @@ def _check_fine(tmp, lib, oracle, interphase_driver, fine_driver, atol, env=None
         assert c["time"] == pytest.approx(step * 1e-7, abs=1e-18)
         assert c["bead_scale"] == 1.0 and c["bond_scale"] == 1.0               # simulation_driver.cc:55-56
         assert np.allclose(c["wall_semiaxes"], semi, rtol=0, atol=max(atol * 1e-3, 1e-12))
-        assert c["mean_energy"] == pytest.approx(e, rel=1e-12 if atol == 0 else 1e-3)
+        if atol == 0:
+            assert c["mean_energy"] == e, step
+        else:
+            assert c["mean_energy"] == pytest.approx(e, rel=1e-3)
     # T = 0: deterministic descent, the energy does not increase between samples
     es = [ref[k][2] for k in sorted(ref)]
     assert all(e1 <= e0 + 1e-9 for e0, e1 in zip(es, es[1:]))

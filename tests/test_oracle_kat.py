@@ -347,3 +347,49 @@ def test_replica_seeds_reproduce_solo_runs(oracle):
     sc.begin_phase()
     sc.run(6, dt, kT, seed=int(seeds[0]), flags=flags)
     assert np.array_equal(sc.positions()[0], xb[0]) and not np.array_equal(sc.positions()[2], xb[2])
+
+
+def test_deferred_callback_is_the_reference_observation_point(oracle):
+    """GD_RUN_DEFER_CALLBACK: after the run the positions are those of step k and the context is what callback(k-1) left --
+    what the reference's callback(k) sees when it computes mean_energy and saves the context, before update_bead_scale() /
+    update_wall_semiaxes() (simulation_driver_interphase.cc:20-22 vs :42-43).  Applying the pending callback -- explicitly,
+    by the next run, or by a force evaluation -- gives the state of an undeferred run bit for bit."""
+    from util import build
+    sa, dt, kT, flags = build(oracle, "genome")
+    sb, *_ = build(oracle, "genome")
+    for s in (sa, sb):
+        s.begin_phase()
+    sa.run(7, dt, kT, seed=3, flags=flags)
+    sb.run(6, dt, kT, seed=3, flags=flags)
+    c6 = sb.context()
+    sb.run(1, dt, kT, seed=3, flags=flags | g.RUN_DEFER_CALLBACK)
+    cp = sb.context()
+    assert cp.callback_pending == 1 and cp.step == 6
+    assert cp.bead_scale == c6.bead_scale and tuple(cp.semiaxes) == tuple(c6.semiaxes)       # the context callback(6) left
+    assert np.array_equal(sb.positions(), sa.positions())                                      # ... with the positions of step 7
+    e_deferred = sb.energy()[0]
+    assert e_deferred != sa.energy()[0]                                                        # (the scales moved in callback(7))
+    # the same number from first principles: positions of step 7 under the context of step 6
+    sc, *_ = build(oracle, "genome")
+    sc.set_positions(sa.positions())
+    sc.set_context(0, 6, c6.bead_scale, c6.bond_scale, tuple(c6.semiaxes))
+    assert sc.energy()[0] == e_deferred
+    sb.apply_callback()
+    ca, cb = sa.context(), sb.context()
+    assert cb.callback_pending == 0 and cb.step == ca.step == 7 and cb.time == ca.time
+    assert cb.bead_scale == ca.bead_scale and cb.bond_scale == ca.bond_scale and tuple(cb.semiaxes) == tuple(ca.semiaxes)
+    assert sb.energy()[0] == sa.energy()[0]
+    # the next run applies a pending callback itself; so does a force evaluation
+    for how in ("run", "forces"):
+        s1, *_ = build(oracle, "genome")
+        s2, *_ = build(oracle, "genome")
+        for s in (s1, s2):
+            s.begin_phase()
+        s1.run(5, dt, kT, seed=4, flags=flags)
+        s2.run(5, dt, kT, seed=4, flags=flags | g.RUN_DEFER_CALLBACK)
+        if how == "forces":
+            assert np.array_equal(s1.forces(), s2.forces()) and s2.context().callback_pending == 0
+        s1.run(5, dt, kT, seed=4, flags=flags)
+        s2.run(5, dt, kT, seed=4, flags=flags)
+        assert np.array_equal(s1.positions(), s2.positions())
+        assert tuple(s1.context().semiaxes) == tuple(s2.context().semiaxes) and s2.context().step == 10

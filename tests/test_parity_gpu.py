@@ -411,6 +411,37 @@ def test_callback_scales_host_and_device_paths(hip, oracle):
         assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
 
 
+@pytest.mark.parametrize("path", ["generic", "tiled"])
+def test_deferred_callback_matches_oracle(hip, oracle, path):
+    """GD_RUN_DEFER_CALLBACK on the device (the callback stays pending in the device context; k_ctx or the next launch applies
+    it): context, energy at the reference's observation point and the continued trajectory against the oracle, across a chunk
+    boundary and a list rebuild."""
+    _, kw, dt, kT, flags = CASES["genome"]
+    out = []
+    for lib in (hip, oracle):
+        s, _ = wl.genome_interphase(lib, n_replicas=2, **kw)
+        if lib is hip:
+            s.set_tuning(kernel_path=PATHS[path])
+        s.begin_phase()
+        rec = []
+        for n in (1, 9, 40):
+            s.run(n, dt, kT, seed=SEED, flags=flags | g.RUN_DEFER_CALLBACK)
+            c = s.context(1)
+            rec.append((c.step, c.callback_pending, c.bead_scale, tuple(c.semiaxes), s.energy().copy()))
+            if n == 9:
+                s.apply_callback()
+                assert s.context(1).callback_pending == 0 and s.context(1).step == c.step + 1
+        s.run(3, dt, kT, seed=SEED, flags=flags)
+        out.append((rec, s.positions(), s.context(0)))
+    (rh, xh, ch), (ro, xo, co) = out
+    for (sh_, ph, bh, semh, eh), (so_, po, bo, semo, eo) in zip(rh, ro):
+        assert sh_ == so_ and ph == po == 1 and bh == bo
+        assert np.allclose(semh, semo, rtol=0, atol=1e-8)
+        assert np.all(np.abs(eh - eo) <= 3 * ENERGY_RTOL * np.abs(eo).sum() + 1e-3)
+    assert ch.step == co.step == 53 and ch.callback_pending == 0
+    assert np.abs(xh - xo).max() <= 1e-4           # 53 noisy steps of a dense system (fp32 vs fp64 divergence)
+
+
 # ---------------------------------------------------------------- BASELINE sizes
 
 def test_full_size_genome_properties(hip):
@@ -618,3 +649,31 @@ def test_equilibrium_statistics_match_oracle(hip, oracle):
     assert bh == pytest.approx(bo, rel=0.02)
     assert rh == pytest.approx(ro, rel=0.01)
     assert np.allclose(ah, ao, rtol=2e-3)                   # the wall ODE integrates the same mean reaction
+
+
+def test_dense_cluster_beyond_the_tiled_record_falls_back(hip, oracle):
+    """A bead with more neighbours in ONE list class than the tiled record can count (31 chunks = 248 entries) while the row
+    is wide enough for the sum: the build must flag it and leave the tiled path, not clamp the chunk count (forces and
+    contact pairs would silently miss neighbours).  360 beads in a ball of radius 0.1 (every pair inside the near radius)
+    + a dilute background, list width 400, tiled path requested."""
+    rng = np.random.default_rng(11)
+    n_core, n = 360, 1200
+    v = rng.normal(size=(n_core, 3))
+    core = 0.1 * v / np.linalg.norm(v, axis=1)[:, None] * rng.random((n_core, 1)) ** (1 / 3)
+    x = np.concatenate([core, (rng.random((n - n_core, 3)) - 0.5) * 6.0]).astype(np.float32).astype(np.float64)
+    out = []
+    for lib in (hip, oracle):
+        s = g.System(lib, n, 1)
+        s.set_bead_params(a=(np.arange(n) % 2).astype(float), b=((np.arange(n) + 1) % 2).astype(float))
+        s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
+        if lib is hip:
+            s.set_tuning(kernel_path=2, list_width=400)
+        s.set_positions(x)
+        out.append((s.forces(), s.energy(), {tuple(p) for p in s.search_pairs(0.3)}, s.context().list_path))
+    (Fh, Eh, Ph, path), (Fo, Eo, Po, _) = out
+    assert np.abs(Fh - Fo).max() <= FORCE_RTOL * np.abs(Fo).max()
+    assert abs(Eh[0] - Eo[0]) <= 1e-5 * abs(Eo[0])
+    for i, j in Ph ^ Po:
+        assert abs(np.linalg.norm(x[i] - x[j]) - 0.3) < 1e-6
+    assert len(Po) > n_core * (n_core - 1) // 2 - 10
+    assert path == 1          # generic lists: the tiled record cannot hold this bead
