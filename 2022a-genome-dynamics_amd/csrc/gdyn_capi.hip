@@ -509,12 +509,14 @@ extern "C" int gd_set_context(gd_system *s, uint32_t r, int64_t step, double bea
 extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
 {
     if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
+    if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");      // (validated before any state changes)
+    if (t->near_fraction < 0 || t->near_fraction > 1) return fail(GD_EINVAL, "gd_set_tuning: near_fraction must be in [0,1]");
     if (t->skin > 0) s->skin = t->skin;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
+    if (t->near_fraction > 0) s->near_frac = t->near_fraction;
     s->a2_ema = 0;
     s->adapt = t->adapt_interval;
     if (t->list_width > 0 && t->list_width != s->W) { (void)s->nbr.resize(0); s->W = t->list_width; }
-    if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");
     s->kernel_path = t->kernel_path; s->tiled_ok = true; s->tiled_off = 0;
     s->list_valid = false;
     return GD_OK;

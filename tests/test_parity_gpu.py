@@ -677,3 +677,94 @@ def test_dense_cluster_beyond_the_tiled_record_falls_back(hip, oracle):
         assert abs(np.linalg.norm(x[i] - x[j]) - 0.3) < 1e-6
     assert len(Po) > n_core * (n_core - 1) // 2 - 10
     assert path == 1          # generic lists: the tiled record cannot hold this bead
+
+
+# ---------------------------------------------------------------- trajectories at scale, at the benchmark's cadence
+
+POS_ATOL_42STEP = 1e-4      # |dx| after 42 noisy steps, fp32 device vs fp64 oracle (dense soft spheres: errors grow ~ e^(0.1 step))
+
+
+def _adapted_state(hip, R, steps=350):
+    """S-genome-30k x R on the device after `steps` steps: rebuild interval adapted from complete intervals (about 14)."""
+    s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    s.begin_phase()
+    s.run(steps, info["timestep"], info["temperature"], seed=SEED + 1, flags=flags)
+    return s, info, flags
+
+
+def test_adapted_interval_trajectory_matches_oracle(hip, oracle):
+    """16 x 30 000 beads, tiled path, at the cadence the benchmark runs at: the interval adapted to ~14 steps, 42 noisy steps
+    = three complete intervals, each ending with the steps in which the far list class joins (gdyn_kernels.hip, pair loop),
+    against the fp64 oracle started from the same positions and context."""
+    R = 16
+    sh, info, flags = _adapted_state(hip, R)
+    c0 = sh.context()
+    K = c0.rebuild_interval
+    assert 8 <= K <= 24 and c0.list_path == 2, (K, c0.list_path)
+    so, _ = wl.genome_interphase(oracle, n_beads=30000, n_replicas=R)
+    so.set_positions(sh.positions())
+    for r in range(R):
+        c = sh.context(r)
+        so.set_context(r, c.step, c.bead_scale, c.bond_scale, tuple(c.semiaxes))
+    for s in (sh, so):
+        s.run(42, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+    c1 = sh.context()
+    assert c1.rollbacks == c0.rollbacks and c1.rebuilds - c0.rebuilds >= 42 // (K + 2), (c0.rebuilds, c1.rebuilds, K)
+    assert c1.list_path == 2
+    assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_42STEP
+    for r in range(R):
+        assert sh.context(r).step == so.context(r).step
+        assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(r).semiaxes), rtol=0, atol=1e-8), r
+
+
+def test_far_class_rule_against_both_classes_every_step(hip):
+    """The far list class is skipped while it cannot matter (d0 >= cutoff + D_i + D): the same state stepped over three
+    intervals of 11 steps (a) with the product rule and (b) with a near radius ~ cutoff, i.e. every step walks both classes (what a plain
+    Verlet list does), and (c) on the generic path (one class).  Skipped entries contribute exactly zero, so the trajectories
+    agree to the order of summation -- deterministic (T = 0) and noisy."""
+    R = 16
+    s0, info, flags = _adapted_state(hip, R)
+    x0 = s0.positions()
+    ctx = [s0.context(r) for r in range(R)]
+    s0.close()
+    for noise, kT in ((g.NOISE_ZERO, 0.0), (g.NOISE_PHILOX, info["temperature"])):
+        out = []
+        for tune in (dict(kernel_path=2), dict(kernel_path=2, near_fraction=1e-3), dict(kernel_path=1)):
+            s, _ = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
+            s.set_tuning(rebuild_interval=11, adapt_interval=0, **tune)
+            s.set_positions(x0)
+            for r in range(R):
+                s.set_context(r, ctx[r].step, ctx[r].bead_scale, ctx[r].bond_scale, tuple(ctx[r].semiaxes))
+            s.run(33, info["timestep"], kT, seed=SEED, noise=noise, flags=flags)
+            c = s.context()
+            # (a fresh handle may size its tile / list width with one rolled-back chunk; a skin violation would cut the interval)
+            assert c.rollbacks <= 1 and c.list_path == tune["kernel_path"] and c.rebuild_interval == 11, (c.rollbacks, c.list_path, c.rebuild_interval)
+            out.append(s.positions())
+            s.close()
+        assert np.abs(out[0] - out[1]).max() <= POS_ATOL_20STEP, noise          # product rule vs both classes every step
+        assert np.abs(out[0] - out[2]).max() <= POS_ATOL_20STEP, noise          # tiled vs generic
+
+
+@pytest.mark.parametrize("n_beads", [62178, 250000])
+def test_full_size_noisy_trajectories(hip, oracle, n_beads):
+    """Five noisy steps at the production bead count of the whole-genome model and at the size of the 1 kb chromosome
+    (periodic box, loops and glues), device vs oracle."""
+    if n_beads == 62178:
+        sh, info = wl.genome_interphase(hip, n_beads=n_beads, bead_scale_init=0.8)
+        so, _ = wl.genome_interphase(oracle, n_beads=n_beads, bead_scale_init=0.8)
+        flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    else:
+        sh, info = wl.chromatin_1kb(hip, n_beads=n_beads)
+        so, _ = wl.chromatin_1kb(oracle, n_beads=n_beads)
+        flags = 0
+    for s in (sh, so):
+        s.begin_phase()
+        s.run(5, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+    xh, xo = sh.positions(), so.positions()
+    d = xh - xo
+    if n_beads == 250000:
+        L = float(info["box"])
+        d -= L * np.rint(d / L)              # a bead within rounding of the box face may be wrapped on one side only
+    assert np.abs(d).max() <= POS_ATOL_20STEP * max(1.0, np.abs(xo).max() / 8)
+    assert sh.context().step == so.context().step == 5
