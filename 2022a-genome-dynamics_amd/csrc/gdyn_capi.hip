@@ -146,6 +146,17 @@ struct gd_system {
     float rn = 0;                   // near-class radius of the tiled list in use
     double a2_ema = 0;              // running mean of (largest displacement)^2 per step of an interval (interval adaptation; 0: none yet)
     double last_dt = 0, last_kT = -1;
+    // Skin selection by measured cost (per workload): a few candidate widths are each run for a few verified chunks once the
+    // rebuild interval has settled, the device time per step decides (gd_run, tune_skin).  Results do not depend on the skin
+    // (verified lists + rollback), only the cost does.
+    struct SkinTuner {
+        bool enabled = true, done = false;
+        std::vector<double> cand, cost;
+        size_t idx = 0;
+        int settle = 0, measured = 0, wait = 8, rounds = 0;      // wait: accepted chunks before the (next) sweep may start
+        uint32_t K_ref = 0;                                      // rebuild interval when the last sweep ended
+        double acc_ms = 0; uint64_t acc_steps = 0;
+    } tuner;
     double pend_dt = 0; int pend_flags = 0;      // timestep and flags of the run that left its last callback pending (GD_RUN_DEFER_CALLBACK)
     double near_frac = 0.65;        // near-class radius = cutoff + near_frac x (list radius - cutoff)
     // gd_search_pairs: device output, counters, and the cached result of the last call
@@ -190,7 +201,8 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     s->lcount.assign(s->R, 0ull);
     s->ncell_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8ull * s->N, 4096ull), 262144ull);
     if (const char *e = dev_env("GDYN_NEAR_FRAC")) s->near_frac = atof(e);
-    if (const char *e = dev_env("GDYN_SKIN")) s->skin = atof(e);
+    if (const char *e = dev_env("GDYN_SKIN")) { s->skin = atof(e); s->tuner.enabled = false; }
+    if (dev_env("GDYN_NO_SKIN_TUNER")) s->tuner.enabled = false;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(GD_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     const size_t RNp = (size_t)s->R * s->Np, RN = (size_t)s->R * s->N;
@@ -511,8 +523,9 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
     if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");      // (validated before any state changes)
     if (t->near_fraction < 0 || t->near_fraction > 1) return fail(GD_EINVAL, "gd_set_tuning: near_fraction must be in [0,1]");
-    if (t->skin > 0) s->skin = t->skin;
+    if (t->skin > 0) { s->skin = t->skin; s->tuner.enabled = false; }      // an explicit width is kept
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
+    if (!t->adapt_interval) s->tuner.enabled = false;                        // a fixed cadence: nothing to select for
     if (t->near_fraction > 0) s->near_frac = t->near_fraction;
     s->a2_ema = 0;
     s->adapt = t->adapt_interval;
@@ -785,7 +798,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // keeps the larger class for a while, so the margin for the smaller class can be thin)
         unsigned want = pick_tile_cap(need_t + 24);
         if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
-        if (s->box_kind == GD_BOX_PERIODIC && want > 5072u) { s->tiled_ok = false; s->tiled_off = 2; }      // (see the overflow branch below)
+        if (s->box_kind == GD_BOX_PERIODIC && want > 5072u) { s->tiled_ok = false; s->tiled_off = 1; }      // (see the overflow branch below)
         else if (want != s->tile_cap && want <= 8192u) {
             if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
@@ -797,7 +810,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // image per pair: with one resident block per CU they lose to the generic path (measured on S-1kb-250k)
         const unsigned cap_max = s->box_kind == GD_BOX_PERIODIC ? 5072u : 8192u;
         if (cap <= cap_max) { s->tile_cap = cap; s->tile_hold = 4; }
-        else { s->tiled_ok = false; s->tiled_off = s->box_kind == GD_BOX_PERIODIC ? 2 : 1; }     // too dense for one tile: generic path
+        else { s->tiled_ok = false; s->tiled_off = 1; }     // too dense for one tile: generic path (retried later with back-off)
     }
     if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
     else if (!tover && need_w > 0) {
@@ -895,6 +908,60 @@ static int apply_pending(gd_system *s)
     GDCHK(download_ctx(s));
     s->state_serial++;
     return GD_OK;
+}
+
+// Interval the skin admits at the measured displacement rate (the adaptation formula of gd_run)
+static uint32_t interval_for_skin(const gd_system *s, double skin)
+{
+    if (!(s->a2_ema > 0)) return s->K;
+    const double lim = 0.5 * pair_cutoff(s) * skin, k = 0.90 * lim * 0.90 * lim / s->a2_ema;
+    return (uint32_t)std::max(1.0, std::min(200.0, std::floor(k)));
+}
+
+// One accepted chunk of `steps` steps took `ms` on the device.  Candidates: the width in use and 0.7 / 0.5 / 0.35 of it (shorter
+// lists and smaller LDS tiles against more frequent builds; a periodic box whose tiles did not fit may fit them at a smaller
+// width).  Each candidate: two chunks to settle (tile class, list width, interval), three measured.  The width the sweep
+// started from is left only for a gain of 8 % or more (chunk times scatter by a few per cent).
+static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval, bool rolled_back)
+{
+    auto &t = s->tuner;
+    if (!t.enabled || s->sw_n) return;
+    if (rolled_back) { t.settle = std::max(t.settle, 1); t.acc_ms = 0; t.acc_steps = 0; t.measured = 0; return; }
+    if (!full_interval || !(s->a2_ema > 0)) return;
+    if (t.done) {      // conditions drift (a relaxation, a growing bead scale): look again, around the width in use, once the
+                       // rebuild interval -- the displacement rate -- has moved by a third since the last sweep
+        if (t.wait > 0) t.wait--;
+        const double k = (double)s->K, k0 = (double)std::max(t.K_ref, 1u);
+        if (t.wait > 0 || (k < 1.33 * k0 && k0 < 1.33 * k)) return;
+        t.done = false; t.cand.clear();
+    }
+    if (t.cand.empty()) {
+        if (t.wait > 0 && t.rounds == 0) { t.wait--; return; }
+        if (t.rounds == 0) t.cand = {s->skin, 0.7 * s->skin, 0.5 * s->skin, 0.35 * s->skin};
+        else t.cand = {s->skin, std::min(1.4 * s->skin, 1.0), 0.7 * s->skin};
+        t.cost.assign(t.cand.size(), 0.0);
+        t.idx = 0; t.settle = 0; t.measured = 0; t.acc_ms = 0; t.acc_steps = 0; t.rounds++;
+    }
+    if (t.settle > 0) { t.settle--; return; }
+    t.acc_ms += ms; t.acc_steps += (uint64_t)steps; t.measured++;
+    if (t.measured < 3) return;
+    t.cost[t.idx] = t.acc_ms / (double)t.acc_steps;
+    if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] skin %.3f: %.4f ms per step (K %u, %s, W %u, tile %u)\n", t.cand[t.idx], t.cost[t.idx], s->K,
+                                       s->list_tiled ? "tiled" : "generic", s->list_W, s->list_tile_cap);
+    size_t next = t.idx + 1;
+    while (next < t.cand.size() && (t.cand[next] == s->skin || interval_for_skin(s, t.cand[next]) < 2)) next++;
+    if (next >= t.cand.size()) {      // sweep complete: the cheapest, but the width the sweep started from unless the gain is 8 % or more
+        size_t best = 0;
+        for (size_t k = 1; k < t.cand.size(); k++) if (t.cost[k] > 0 && t.cost[k] < 0.92 * t.cost[0] && t.cost[k] < t.cost[best]) best = k;
+        next = best; t.done = true; t.wait = 50; t.K_ref = interval_for_skin(s, t.cand[best]);
+    }
+    if (t.cand[next] != s->skin) {
+        s->skin = t.cand[next];
+        s->K = interval_for_skin(s, s->skin); s->K_bad_ttl = 0;
+        s->list_valid = false;
+        if (s->kernel_path != 1 && s->packed_ab) { s->tiled_ok = true; s->tiled_off = 0; }      // smaller tiles may fit now
+    }
+    t.idx = next; t.settle = 2; t.measured = 0; t.acc_ms = 0; t.acc_steps = 0;
 }
 
 extern "C" int gd_apply_callback(gd_system *s)
@@ -1041,6 +1108,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 } else { s->K_bad = s->K; s->K_bad_ttl = 64; s->K = std::max(1u, s->K - std::max(1u, s->K / 4)); s->a2_ema = 0; }   // (a gentler cut, K/8 for 32 chunks, violates again sooner: measured 1% slower)
             }
             s->timing.step_launches -= std::min<uint64_t>(s->timing.step_launches, (uint64_t)chunk);
+            tune_skin(s, 0.0, 0, false, true);
             continue;
         }
         // accepted: timing, context mirror, cadence adaptation
@@ -1050,7 +1118,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             // try it again at the next build, with the largest tile class; a new overflow costs one rolled-back chunk
             // and doubles the waiting time
             s->tiled_ok = true; s->tiled_off = 0; s->tiled_wait = 0; s->tiled_backoff = std::min(2 * s->tiled_backoff, 1024u);
-            s->tile_cap = 8192u;
+            s->tile_cap = s->box_kind == GD_BOX_PERIODIC ? 5072u : 8192u;
         }
         float ms = 0;
         for (auto &sp : spans) {
@@ -1082,6 +1150,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             } else if (d == 0) s->K = std::min(200u, s->K * 2);
             if (s->K_bad_ttl > 0) { s->K_bad_ttl--; if (s->K >= s->K_bad) s->K = std::max(1u, s->K_bad - 1); }
         }
+        if (with_list) tune_skin(s, ms, chunk, full_interval, false);
         done += chunk;
     }
     return GD_OK;

@@ -17,17 +17,14 @@
 //                          slot order, tile descriptors, list fill (27-cell sweep from the LDS tile, or from global
 //                          memory on the generic path).
 //   k_pairs                pair search (contact map, glue candidates) filtered from the resident list.
-//   GD_ABL                 timing-only builds (tools/abl.sh): term ablations 11-15, section stamps 30 / 34.
+//   GD_STAMP / GD_FSTAMP   in-kernel section stamps of the developer timing builds (gdyn_stamps.h; empty in the product).
 //
 // MFMA is not used: the path is an irregular short-range N-body sum.
 #include <hip/hip_fp16.h>
 
 #include "gdyn_types.h"
 
-#ifndef GD_ABL
-#define GD_ABL 0   // timing-only builds (never shipped): 2 = no sweep, 3 = 2 + no bond re-map, 4 = 3 + no tile staging, 11-15 = one force
-                   // term removed, 30 / 34 = in-kernel section stamps of k_step / k_fill
-#endif
+#include "gdyn_stamps.h"
 
 #define TERM_PAIR 1u
 #define TERM_BOND 2u
@@ -312,14 +309,6 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
 }
 
 // ------------------------------------------------------------------- k_step
-// GD_ABL == 30 (timing-only build): per-section shader-clock stamps, summed per wave into the (otherwise unused in
-// step mode) force-output buffer; read back by gd_debug_bench(what >= 10).
-#if GD_ABL == 30
-#define GD_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] = now_ - tprev_; tprev_ = now_; } while (0)
-#else
-#define GD_STAMP(k) do { } while (0)
-#endif
-
 // TILED: the block first stages its LDS tile (its own 256 slots + all slots of the adjacent
 // cells, 9 contiguous slot ranges, TileDesc) with coalesced loads; pair-list entries are 16-bit
 // indices into that tile, so the neighbour gather is an LDS read.  PK=1/2: softcore<2,3>+<8,3>
@@ -347,23 +336,10 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     const unsigned tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t rbase = (size_t)r * p.Np;
     const float4 *__restrict__ rpos = p.pos_in + rbase;
-#if GD_ABL == 43 || GD_ABL == 44
-    if (blockIdx.x < 768u) {      // stagger the first round of blocks by their wave slot (first / second / third block of the CU)
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        const unsigned k = (hwid & 0xfu) >> 1;
-        for (unsigned i = 0; i < k && i < 3u; i++) { __builtin_amdgcn_s_sleep(127); if (GD_ABL == 44) __builtin_amdgcn_s_sleep(127); }
-    }
-#endif
-#if GD_ABL == 40
-    __builtin_amdgcn_s_setprio(3);
-#endif
 
     // every independent per-bead load is issued up front, ahead of the tile staging and the barrier,
     // so their latencies overlap (the kernel is latency-bound, not ALU-bound)
-#if GD_ABL == 30
-    unsigned long long tprev_ = __builtin_amdgcn_s_memtime(), acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
+    GD_STAMP_BEGIN();
     // replica context: the two scalars every wave needs (noise counter) are fetched here, before any DMA, so that they
     // stay scalar loads; wave 0 also starts its full-context and reaction-partial loads first
     const long long ctx_step0 = p.ctx_in[r].step;
@@ -397,11 +373,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         // the record is consumed HERE (an empty asm the compiler has to wait in front of), while it is still the only
         // vector load in flight: placed behind the DMAs, its wait would be a wait for the whole tile.  Its latency
         // overlaps the scalar descriptor loads above.
-#if GD_ABL != 45
         asm volatile("" : "+v"(mo.x), "+v"(mo.y));
-#endif
         GD_STAMP(9);      // record + descriptor arrived
-        if (GD_ABL != 12 && (GD_ABL != 33 || (blk & 3u) == 0)) {
+        {
             // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
             // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
             // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
@@ -457,23 +431,17 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     // and the per-bead loads are in flight (the step index comes from a uniform scalar load).  Tiled path: whether the
     // thread owns a bead is not known yet (that is in the build-position record); threads without one have bead id 0.
     float3 z = make_float3(0.f, 0.f, 0.f);
-    if (MODE == GD_MODE_STEP && GD_ABL != 14 && (GD_ABL == 45 || (TILED ? oid != GD_REC_NOBEAD : valid)) && p.kT > 0.f) {
+    if (MODE == GD_MODE_STEP && (TILED ? oid != GD_REC_NOBEAD : valid) && p.kT > 0.f) {
         if (p.noise_mode == NOISE_PHILOX) {
             const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
-#if GD_ABL == 45      // timing only: the noise does not wait for the record (upper bound of taking the record load off the critical path)
-            z = philox_normal3(p.seed, (unsigned)gt, step_now + 1, r);
-#else
             z = p.seeds ? philox_normal3(p.seeds[r], oid, step_now + 1, 0u) : philox_normal3(p.seed, oid, step_now + 1, r);
-#endif
         } else if (p.noise_mode == NOISE_HOST) {
             const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
             z = make_float3(h[0], h[1], h[2]);
         }
     }
-#if GD_ABL == 30
-    asm volatile("" :: "v"(z.x), "v"(z.y), "v"(z.z));
+    GD_STAMP_USE3(z.x, z.y, z.z);
     GD_STAMP(10);     // noise
-#endif
     // wave 0: pending callback + float copy of the context for the block.  After the noise: its vector loads sit behind the
     // DMAs in the vmcnt order, so this is where wave 0 waits for its share of the tile
     if (wid == 0) {
@@ -485,13 +453,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         if (lane == 0) fill_ctxf(s_ctx, c, p);
     }
     GD_STAMP(0);      // prologue: loads issued, tile DMA issued, noise
-#if GD_ABL == 40
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __syncthreads();
-#if GD_ABL == 41
-    __builtin_amdgcn_s_setprio(2);
-#endif
     GD_STAMP(1);      // barrier (tile arrival)
     if (TILED) {
         valid = oid != GD_REC_NOBEAD;
@@ -519,7 +481,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         const float2 abi = p.packed_ab ? unpack_ab(xi4.w) : p.ab[g];
 
         // ---- non-bonded pairs over the Verlet list (a3, a5)
-        if (GD_ABL != 11 && p.pair.enabled && (mask & TERM_PAIR)) {
+        if (p.pair.enabled && (mask & TERM_PAIR)) {
             const float inv_sa2 = s_ctx.p_inv_sa2, inv_sb2 = s_ctx.p_inv_sb2;      // (block-uniform: computed once, fill_ctxf)
             const float cut = s_ctx.p_cut, cut2 = cut * cut;
             const float ca = 6.0f * p.pair.eps_a * inv_sa2, cb = 24.0f * p.pair.eps_b * inv_sb2;
@@ -580,10 +542,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                 if (GD_HALF != (int)GD_UNROLL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = uh; u < uh + GD_HALF; u++) {
-                    if (GD_ABL == 22) xjv[u] = s_tile[(threadIdx.x + 64u * u + k0) & 2047u];          // conflict-free LDS reads
-                    else if (GD_ABL == 23) xjv[u] = make_float4(xi.x + 0.01f * (float)(jj[u] & 15u), xi.y + 0.02f, xi.z, xi4.w);   // no LDS
-                    else if (GD_ABL == 42) { const float2 lo = *(const float2 *)((const char *)s_tile + (jj[u] >> 1)); xjv[u] = make_float4(lo.x, lo.y, xi.z + 0.01f, xi4.w); }   // 8-byte entries: LDS side only
-                    else xjv[u] = !TILED ? rpos[jj[u]] : S16 ? *(const float4 *)((const char *)s_tile + jj[u]) : s_tile[jj[u]];
+                    xjv[u] = !TILED ? rpos[jj[u]] : S16 ? *(const float4 *)((const char *)s_tile + jj[u]) : s_tile[jj[u]];
                 }
 #pragma unroll
                 for (int u = uh; u < uh + GD_HALF; u++) {
@@ -600,8 +559,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                             waca = fmaf(abj.x, hca, Ai); wbcb = fmaf(abj.y, hcb, Bi);      // (a_i+a_j)/2 * ca, (b_i+b_j)/2 * cb
                             if (MODE == GD_MODE_ENERGY) { wa = 0.5f * (abi.x + abj.x); wb = 0.5f * (abi.y + abj.y); }
                         }
-                        const float f = GD_ABL == 21 ? waca * fmaxf(fmaf(-r2, inv_sa2, 1.0f), 0.0f)
-                                      : GD_ABL == 24 ? r2 : softcore_2383(r2, inv_sa2, inv_sb2, waca, wbcb);
+                        const float f = softcore_2383(r2, inv_sa2, inv_sb2, waca, wbcb);
                         F.x = fmaf(f, d.x, F.x); F.y = fmaf(f, d.y, F.y); F.z = fmaf(f, d.z, F.z);
                         if (MODE == GD_MODE_ENERGY && (TILED ? j != self_e : k0 + u < cnt))
                             E += 0.5f * softcore_2383_energy(r2, inv_sa2, inv_sb2, p.pair.eps_a, p.pair.eps_b, wa, wb);
@@ -624,7 +582,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
 
         GD_STAMP(2);  // pair loop
         // ---- bonded pairs (a6, a12): per-bead adjacency, each bond evaluated from both ends
-        if (GD_ABL != 13 && p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
+        if (p.has_bonds && (mask & (TERM_BOND | TERM_DYNAMIC))) {
             const unsigned deg = meta & 0xffu;
             const float inv_bs2 = s_ctx.inv_bond_scale2;
             if (TILED) {
@@ -790,7 +748,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         GD_STAMP(4);  // bending + point sources
         // ---- ellipsoid wall (a9): second-order nearest-surface construction
         // (5-sim-genome/src/analyze_lamina/geometry.py:13-28), conjugate form u = C/(B+sqrt(B^2-AC)).
-        if (GD_ABL != 15 && p.wall.enabled && (mask & TERM_WALL)) {
+        if (p.wall.enabled && (mask & TERM_WALL)) {
             const float ia = s_ctx.inv_semi2[0], ib = s_ctx.inv_semi2[1], ic = s_ctx.inv_semi2[2];
             const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);
             const float C1 = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z, C = C1 - 1.0f;
@@ -871,13 +829,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     }
 
     GD_STAMP(6);      // integrate + store
-#if GD_ABL == 30
-    if ((threadIdx.x & 63) == 0) {      // one record per wave, plain stores
-        unsigned long long *rec = (unsigned long long *)p.fout + ((size_t)blockIdx.x * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 16;
-        for (int k = 0; k < 12; k++) rec[k] = acc_[k];
-        rec[15] = 1ull;
-    }
-#endif
+    GD_STAMP_END((unsigned long long *)p.fout);
     // ---- block reductions: wall reaction partial (deterministic), energy, max displacement
     // running maximum of the displacement since the build, for the far-class test of the NEXT step: one atomic per block
     // (folded into the reaction reduction) or per wave, only from those that raise the value this launch started from, each
@@ -1222,29 +1174,45 @@ __global__ void k_tiles(const BuildParams p)
         // Periodic boxes: the tile is made of WHOLE rows of cells (a row = fixed (z,y), all x; the x-neighbours of the
         // first and last cell of a row are in the same row).  Rows needed = the 3 x 3 (dz,dy) neighbours, wrapped, of
         // every row the block touches; consecutive rows are contiguous in slot order and merge into one range.
-        const int nx = gp.nc[0], ny = gp.nc[1], nz = gp.nc[2], nrows = ny * nz;
+        const int nx = gp.nc[0], ny = gp.nc[1], nz = gp.nc[2];
         const int r0 = c0 / nx, r1 = c1 / nx;
-        unsigned bits[64];                               // row bitmap (<= 2048 rows; larger grids take the generic path)
-        bool ok = nrows <= 2048 && nx >= 3 && ny >= 3 && nz >= 3;
-        for (int i = 0; i < 64; i++) bits[i] = 0;
-        for (int rw = r0; ok && rw <= r1; rw++) {
-            const int z = rw / ny, y = rw % ny;
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int q = ((z + dz + nz) % nz) * ny + (y + dy + ny) % ny;
-                    bits[q >> 5] |= 1u << (q & 31);
-                }
-        }
+        // Runs of consecutive needed rows (a run = one contiguous slot range).  The touched rows r0..r1 are consecutive; inside
+        // one z-plane they are the y-interval [ya, yb], whose neighbour rows in each of the planes z-1, z, z+1 (wrapped) are
+        // the y-interval [ya-1, yb+1] (wrapped: one or two runs, or the whole plane).  The runs of all touched planes are sorted
+        // by their first row and merged.  Any number of touched rows (sparse regions, small boxes); a block that touches more than
+        // GD_TILE_PLANES planes goes to the generic path.
+        constexpr int GD_TILE_PLANES = 10;
+        const int z0 = r0 / ny, z1 = r1 / ny;
+        const bool ok = nx >= 3 && ny >= 3 && nz >= 3 && z1 - z0 + 1 <= GD_TILE_PLANES;
         unsigned total = 0; int nm = 0; bool truncated = !ok;
         for (int k = 0; k < GD_TILE_RANGES; k++) { td.start[k] = 0; td.len[k] = 0; td.base[k] = 0; td.kstart[k] = 0xffffffffu; td.kbase[k] = 0; }
-        if (!ok) {      // grid too small (aliasing neighbours) or too large for the row bitmap: generic path
+        if (!ok) {      // grid too small (aliasing neighbours) or the block spans too many planes: generic path
             if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
             if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], 1u << 20);
         }
-        for (int q = 0; ok && q < nrows; ) {
-            if (!((bits[q >> 5] >> (q & 31)) & 1u)) { q++; continue; }
-            int e = q;
-            while (e + 1 < nrows && ((bits[(e + 1) >> 5] >> ((e + 1) & 31)) & 1u)) e++;
+        int ra[6 * GD_TILE_PLANES], rb[6 * GD_TILE_PLANES], nrun = 0;
+        for (int z = z0; ok && z <= z1; z++) {
+            const int ya = z == z0 ? r0 % ny : 0, yb = z == z1 ? r1 % ny : ny - 1;
+            for (int dz = -1; dz <= 1; dz++) {
+                const int base = ((z + dz + nz) % nz) * ny;
+                if (yb - ya + 3 >= ny) { ra[nrun] = base; rb[nrun++] = base + ny - 1; continue; }
+                const int lo = ya - 1, hi = yb + 1;
+                if (lo < 0) { ra[nrun] = base; rb[nrun++] = base + hi; ra[nrun] = base + ny - 1; rb[nrun++] = base + ny - 1; }
+                else if (hi >= ny) { ra[nrun] = base; rb[nrun++] = base; ra[nrun] = base + lo; rb[nrun++] = base + ny - 1; }
+                else { ra[nrun] = base + lo; rb[nrun++] = base + hi; }
+            }
+        }
+        for (int i = 1; i < nrun; i++) {                    // insertion sort by first row (at most 60 runs, typically 3 to 6)
+            const int va = ra[i], vb = rb[i];
+            int j = i - 1;
+            while (j >= 0 && ra[j] > va) { ra[j + 1] = ra[j]; rb[j + 1] = rb[j]; j--; }
+            ra[j + 1] = va; rb[j + 1] = vb;
+        }
+        for (int i = 0; i < nrun; ) {
+            const int q = ra[i];
+            int e = rb[i];
+            i++;
+            while (i < nrun && ra[i] <= e + 1) { e = max(e, rb[i]); i++; }      // overlapping and adjacent runs merge
             const unsigned st = cs[q * nx], len = cs[(e + 1) * nx] - st;
             if (nm >= GD_TILE_RANGES || total + len > p.tile_cap) {
                 if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
@@ -1255,7 +1223,6 @@ __global__ void k_tiles(const BuildParams p)
             }
             td.start[nm] = st; td.len[nm] = len; td.base[nm] = total;
             total += len; nm++;
-            q = e + 1;
         }
         td.nranges = truncated ? 0u : (unsigned)nm;
         td.total = total;
@@ -1310,17 +1277,10 @@ __global__ void k_tiles(const BuildParams p)
 
 // Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
 // TILED: candidates are read from the block's LDS tile and list entries are tile indices.
-#if GD_ABL == 34
-#define GD_FSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); facc_[k] += now_ - ftprev_; ftprev_ = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define GD_FSTAMP(k) do { } while (0)
-#endif
 template <bool PERIODIC, bool TILED, bool S16>
 __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
-#if GD_ABL == 34
-    unsigned long long ftprev_ = __builtin_amdgcn_s_memtime(), facc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
+    GD_FSTAMP_BEGIN();
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
     __shared__ unsigned s_max[GD_BLOCK / 64];
@@ -1341,7 +1301,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     __shared__ TileDesc s_tdesc;
 #define s_td s_tdesc
     const unsigned o_pre = (TILED && slot < p.N) ? p.orig_out[g] : 0u;      // (issued ahead of the DMAs: the balancing key below depends on it)
-    if (TILED && GD_ABL != 4) {
+    if (TILED) {
         // LDS-DMA staging as in k_step: descriptor by scalar loads first, then all pieces back to back
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
         const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)(wid * 64u));
@@ -1392,7 +1352,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             }
             return false;
         };
-        const unsigned deg = (GD_ABL == 3 || GD_ABL == 4) ? 0u : p.bdeg_o[o];
+        const unsigned deg = p.bdeg_o[o];
         const size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
         uint4 *__restrict__ adjw = (uint4 *)p.badj + (size_t)(gw >> 6) * (p.WB / 4) * 64 + (gw & 63);
         // one 16-byte adjacency chunk per round: its four gathers (entry by bead, then slot by partner) are in flight
@@ -1534,17 +1494,13 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 for (int k = 0; k < GD_TILE_RANGES; k++) {
                     const int zz = cz + k / 3 - 1, yy = cy + k % 3 - 1;
                     rb[k] = 0; re[k] = 0;
-                    if (GD_ABL == 5 || zz < 0 || zz >= gp.nc[2] || yy < 0 || yy >= gp.nc[1] || s_td.kstart[k] == 0xffffffffu) continue;
+                    if (zz < 0 || zz >= gp.nc[2] || yy < 0 || yy >= gp.nc[1] || s_td.kstart[k] == 0xffffffffu) continue;
                     const unsigned row = (unsigned)((zz * gp.nc[1] + yy) * gp.nc[0]);
                     rb[k] = cs[row + x_lo]; re[k] = cs[row + x_hi + 1];
                 }
                 GD_FSTAMP(2);     // row bounds
 #pragma unroll
                 for (int k = 0; k < GD_TILE_RANGES; k++) {
-#if GD_ABL >= 2 && GD_ABL <= 4
-                    asm volatile("" :: "v"(rb[k]), "v"(re[k]));
-                    continue;
-#endif
                     const unsigned b = rb[k], e = re[k];
                     if (e > b) {
                         const unsigned lb = s_td.kbase[k] + (b - s_td.kstart[k]), le = lb + (e - b);
@@ -1560,9 +1516,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             // slots past the window (slack is allocated behind the tile); those bits are shifted out
                             // below, the bead itself is masked once.
                             for (unsigned u0 = 0; u0 < n; u0 += 4) {
-#if GD_ABL == 34
-                                facc_[8] += 1;        // wave-level test groups (lane 0 runs while any lane does)
-#endif
+                                GD_FCOUNT(8);         // wave-level test groups (lane 0 runs while any lane does)
                                 const float4 *cj = s_tile + j0 + u0;
 #pragma unroll
                                 for (int u = 0; u < 4; u++) {
@@ -1579,9 +1533,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             mn &= m; m ^= mn;                                // near class, far class
                             GD_FSTAMP(3);     // distance tests
                             while (mn) {                                     // ascending candidate order
-#if GD_ABL == 34
-                                facc_[9] += 1;
-#endif
+                                GD_FCOUNT(9);
                                 const unsigned bit = 31u - (unsigned)__clz(mn);
                                 mn ^= 1u << bit;
                                 push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
@@ -1670,13 +1622,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
     }
     GD_FSTAMP(6);     // count
-#if GD_ABL == 34
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long *rec = p.dbg + ((size_t)blockIdx.x * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 16;
-        for (int k = 0; k < 12; k++) rec[k] = facc_[k];
-        rec[15] = 1ull;
-    }
-#endif
+    GD_FSTAMP_END(p.dbg);
 }
 
 #undef s_td

@@ -104,6 +104,35 @@ def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
     return base, farm
 
 
+def _kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gdyn_kernels.hip", "gdyn_types.h"):
+        h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _cached_traffic(n_beads, replicas, list_entries_per_bead):
+    """HBM bytes per k_step launch from the committed PMC passes (profiles/*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of
+    this very workload, profiles/README.md).  Counters cannot be read from inside the process, so this is a cached profile value --
+    used only while it describes the kernel being timed: same workload, same kernel source (hash), list length within 5 %."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+            if tj["workload"] != {"n_beads": n_beads, "replicas_per_gpu": replicas}:
+                continue
+            if tj.get("kernel_source_sha") != _kernel_source_sha():
+                continue
+            L0 = tj.get("list_entries_per_bead")
+            if L0 and abs(list_entries_per_bead - L0) > 0.05 * L0:
+                continue
+            return {"bytes": tj["k_step"]["corrected_bytes_per_launch"], "source": "profiles/" + os.path.basename(path)}
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
 def other_workloads(g, wl, hip, dev_index, budget_steps=600):
     """The measurements BASELINE.md / SURVEY 8d list beside the headline, each after its own (short) relaxation, same
     clock as the headline (wall time of gd_run): ms per step, bead-steps/s, rollbacks.  Reported under config.other_workloads."""
@@ -126,8 +155,13 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
         out.append({"workload": tag, "n_beads": N, "replicas": R, "steps": steps, "relax_steps": relax,
                     "bead_steps_per_s": N * R * steps / el, "ms_per_step": el / steps * 1e3,
                     "k_step_ms": tm.step_kernel_ms / max(tm.step_launches, 1), "rebuild_ms_per_step": tm.rebuild_ms / max(tm.step_launches, 1),
-                    "list_entries_per_bead": c.list_entries / N, "rebuild_interval": int(c.rebuild_interval),
+                    "list_entries_per_bead": c.list_entries / N, "rebuild_interval": int(c.rebuild_interval), "list_radius": c.list_radius,
                     "rollbacks_in_timed_steps": int(c.rollbacks - rb0), "kernel_path": {0: "none", 1: "generic", 2: "tiled"}[c.list_path]})
+        tr = _cached_traffic(N, R, c.list_entries / N)
+        if tr:      # a committed PMC pass of this workload exists: HBM fraction of its step kernel, as for the headline
+            gbs = tr["bytes"] / (out[-1]["k_step_ms"] * 1e-3) / 1e9
+            out[-1]["roofline"] = {"bound": "hbm", "kernel": "k_step", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                   "traffic": tr["bytes"], "traffic_source": tr["source"]}
         s.close()
 
     f3 = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
@@ -139,8 +173,11 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, bead_scale_init=0.5, device=dev_index), f3, 4000, budget_steps)
     run_one("S-genome-30k x 128, 2nd-bond spring 0 (variant of SURVEY 8d)",
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, second_bond_spring=0.0, device=dev_index), f3, 4000, budget_steps)
+    # (the list width is selected per workload from measured chunk times: the relaxation is long enough for that sweep)
     run_one("S-1kb-250k x 4 replicas (periodic, loops + glues static)",
-            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=4, device=dev_index), 0, 300, budget_steps // 2)
+            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=4, device=dev_index), 0, 5000, budget_steps)
+    run_one("S-1kb-250k x 16 replicas (as many beads per launch as the headline)",
+            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=16, device=dev_index), 0, 5000, budget_steps)
     return out
 
 
@@ -243,6 +280,16 @@ def main():
     el = farm.max_over_ranks(time.perf_counter() - t0, device=tdev)
     rollbacks_timed = sys_.context(0).rollbacks - rb0
 
+    # steady-state rate: a window of at least 40 rebuild intervals (the timed region of a short run holds one build or two by
+    # chance), time-boxed; reported beside `value`, never instead of it
+    K_now = max(int(sys_.context(0).rebuild_interval), 1)
+    n_ss = min(max(40 * K_now, 400), 4000)
+    farm.barrier(); torch.cuda.synchronize()
+    t_ss = time.perf_counter()
+    sys_.run(n_ss, dt, kT, seed=seed, flags=flags)
+    torch.cuda.synchronize(); farm.barrier()
+    el_ss = farm.max_over_ranks(time.perf_counter() - t_ss, device=tdev)
+
     # second figure: the same stepping with the reference's observation cadence -- mean energy every
     # interphase_logging_interval = 100 steps, a quantised snapshot every interphase_sampling_interval = 1000 steps
     # (config_entries.inc:81-82); 1000 extra steps, not part of `value`
@@ -267,18 +314,11 @@ def main():
     gathered = farm.gather_stats([e_mean, ctx.semiaxes[0], float(ctx.rebuild_interval), float(ctx.rollbacks)], device=tdev)
 
     if rank == 0:
-        # HBM bytes per k_step launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this very
-        # workload, profiles/README.md); a cached profile value, not a measurement of this run: counters cannot be read
-        # from inside the process
-        traffic, traffic_src = None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                if tj["workload"] == {"n_beads": N, "replicas_per_gpu": R}:
-                    traffic, traffic_src = tj["k_step"]["corrected_bytes_per_launch"], "profiles/" + name
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
+        # HBM bytes per k_step launch: the committed PMC passes while they describe this kernel and list (else the algorithmic
+        # figure alone is reported)
+        L_bead = tm.list_entries_visited / max(int(tm.step_launches), 1) / (N * R)
+        tr = _cached_traffic(N, R, L_bead)
+        traffic, traffic_src = (tr["bytes"], tr["source"]) if tr else (None, None)
         launches = max(int(tm.step_launches), 1)
         L_launch = tm.list_entries_visited / launches                 # directed entries, all replicas
         kms = tm.step_kernel_ms / launches                            # HIP events on the handle's stream around the step launches
@@ -299,6 +339,7 @@ def main():
                        "timestep": dt, "temperature": kT, "list_entries_per_bead": L_launch / (N * R),
                        "rebuild_interval": int(ctx.rebuild_interval), "list_radius": ctx.list_radius,
                        "rollbacks": int(ctx.rollbacks), "rollbacks_in_timed_steps": int(rollbacks_timed), "equil_steps": a.equil,
+                       "steady_state_bead_steps_per_s": N * R * world * n_ss / el_ss, "steady_state_steps": n_ss,
                        "bead_steps_per_s_with_reference_cadence_rank0": obs_rate,
                        "mean_energy_per_bead": [float(v[0]) for v in gathered], "wall_semiaxis": [float(v[1]) for v in gathered]},
             # frac = measured HBM bytes of the dominant kernel / its launch time / 8 TB/s (<= 1 by construction); the

@@ -346,7 +346,20 @@ def test_full_size_1kb_vs_oracle(hip, oracle):
     for t in ("pair", "bond", "bend", "dynamic"):
         assert np.abs(sh.forces(TERMS[t]) - so.forces(TERMS[t])).max() <= FORCE_RTOL * scale, t
     eo = so.energy()
-    assert abs(sh.energy()[0] - eo[0]) <= 3 * ENERGY_RTOL * sum(abs(so.energy(TERMS[t])[0]) for t in ("pair", "bond", "bend", "dynamic"))
+    esum = sum(abs(so.energy(TERMS[t])[0]) for t in ("pair", "bond", "bend", "dynamic"))
+    assert abs(sh.energy()[0] - eo[0]) <= 3 * ENERGY_RTOL * esum
+    # the LDS-tiled path of periodic boxes (whole rows of cells) at the list radius it fits at: 53 x 53 = 2 809 rows of cells
+    sh.set_tuning(skin=0.35, kernel_path=2)
+    assert np.abs(sh.forces() - Fo).max() <= FORCE_RTOL * scale
+    assert sh.context().list_path == 2
+    assert abs(sh.energy()[0] - eo[0]) <= 3 * ENERGY_RTOL * esum
+    ph, po = {tuple(p) for p in sh.search_pairs(1.2)}, {tuple(p) for p in so.search_pairs(1.2)}
+    x, L = so.positions()[0], float(info["box"])
+    assert len(po) > 200000 and len(ph ^ po) < 100
+    for i, j in ph ^ po:       # the device holds the positions in fp32 (ulp 7.6e-6 at |x| ~ 100): only pairs that close to the radius
+        d = x[i] - x[j]
+        d -= L * np.rint(d / L)
+        assert abs(np.linalg.norm(d) - 1.2) < 3e-5
 
 
 def test_wall_context_on_a_grid_larger_than_the_chip(hip, oracle):

@@ -1,4 +1,3 @@
-import os
 """Experiment: H handles of R replicas each on ONE GPU, stepped concurrently from H host threads (one HIP stream per handle):
 does the overlap of one handle's list builds / launch tails with another handle's steps raise the aggregate throughput?
 usage: two_handles.py [H] [R per handle] [steps]"""
