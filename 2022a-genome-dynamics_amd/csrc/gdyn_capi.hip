@@ -153,7 +153,7 @@ struct gd_system {
         bool enabled = true, done = false;
         std::vector<double> cand, cost;
         size_t idx = 0;
-        int settle = 0, measured = 0, wait = 8, rounds = 0;      // wait: accepted chunks before the (next) sweep may start
+        int settle = 0, measured = 0, wait = 4, rounds = 0;      // wait: accepted chunks before the (next) sweep may start
         uint32_t K_ref = 0;                                      // rebuild interval when the last sweep ended
         double acc_ms = 0; uint64_t acc_steps = 0;
     } tuner;
@@ -920,7 +920,7 @@ static uint32_t interval_for_skin(const gd_system *s, double skin)
 
 // One accepted chunk of `steps` steps took `ms` on the device.  Candidates: the width in use and 0.7 / 0.5 / 0.35 of it (shorter
 // lists and smaller LDS tiles against more frequent builds; a periodic box whose tiles did not fit may fit them at a smaller
-// width).  Each candidate: two chunks to settle (tile class, list width, interval), three measured.  The width the sweep
+// width).  Each candidate: one chunk to settle (tile class, list width, interval), three measured.  The width the sweep
 // started from is left only for a gain of 8 % or more (chunk times scatter by a few per cent).
 static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval, bool rolled_back)
 {
@@ -961,7 +961,7 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
         s->list_valid = false;
         if (s->kernel_path != 1 && s->packed_ab) { s->tiled_ok = true; s->tiled_off = 0; }      // smaller tiles may fit now
     }
-    t.idx = next; t.settle = 2; t.measured = 0; t.acc_ms = 0; t.acc_steps = 0;
+    t.idx = next; t.settle = 1; t.measured = 0; t.acc_ms = 0; t.acc_steps = 0;
 }
 
 extern "C" int gd_apply_callback(gd_system *s)
@@ -1007,7 +1007,11 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     int64_t done = 0;
     while (done < run->steps) {
         // ---- one verified chunk
-        const int64_t chunk = std::min<int64_t>(run->steps - done, std::min<int64_t>(256, std::max<int64_t>(32, 12ll * s->K)));
+        // (while the skin sweep is measuring candidates the chunks are shorter -- four rebuild intervals -- so that a sweep costs
+        // a few thousand steps, not tens of thousands)
+        const bool sweeping = s->tuner.enabled && !s->tuner.done && !s->tuner.cand.empty();
+        const int64_t chunk = std::min<int64_t>(run->steps - done, sweeping ? std::min<int64_t>(128, std::max<int64_t>(32, 4ll * s->K))
+                                                                            : std::min<int64_t>(256, std::max<int64_t>(32, 12ll * s->K)));
         // snapshot for rollback: positions in bead order + context
         gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->snap.p, s->N, s->Np, s->R, 0, s->stream);
         const std::vector<DevCtx> snap_ctx = s->hctx;

@@ -366,9 +366,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     if (TILED) {
         mo = p.rec_mo[gt];
         const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
-        unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
+        unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES];      // (the LDS base of a range is the sum of the lengths before it: not loaded)
 #pragma unroll
-        for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = td->len[k]; tst[k] = td->start[k]; tbase[k] = td->base[k]; }
+        for (int k = 0; k < GD_TILE_RANGES; k++) { tlen[k] = td->len[k]; tst[k] = td->start[k]; }
         own_base = td->own_base; tile_ok = td->nranges;
         // the record is consumed HERE (an empty asm the compiler has to wait in front of), while it is still the only
         // vector load in flight: placed behind the DMAs, its wait would be a wait for the whole tile.  Its latency
@@ -383,9 +383,10 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             if (wid == 0 && lane < 2 * GD_MAX_BOND_TYPES)       // the bond-type table: 32 B per type, 16 B per lane (the buffer always holds the full table)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)p.btab + lane),
                                                  (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
+            unsigned base = 0;
 #pragma unroll
-            for (int k = 0; k < GD_TILE_RANGES; k++) {
-                const unsigned len = tlen[k], st = tst[k], base = tbase[k];
+            for (int k = 0; k < GD_TILE_RANGES; base += tlen[k], k++) {
+                const unsigned len = tlen[k], st = tst[k];
                 for (unsigned q0 = wq; q0 < len; q0 += GD_BLOCK) {      // (wave-uniform loop: scalar control, one compare per lane)
                     if (q0 + lane < len)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
@@ -421,9 +422,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         if (p.has_bonds) adj0 = adj[0];
         if (p.pair.enabled) { qa = lst[0]; qb = lst[64]; }
     }
-    unsigned local = 0, nA = 0, nB = 0;      // tiled: block-local slot of the thread's bead, chunks of the near and far class
+    unsigned local = 0, nA = 0, nAq = 0, nB = 0;      // tiled: block-local slot of the thread's bead, chunks of the near and far class (nAq: near entries in fours)
     if (TILED) {
-        local = (mo.x >> 12) & 0x1ffu; nA = (mo.x >> 21) & 31u; nB = (mo.x >> 26) & 31u;
+        local = (mo.x >> 12) & 0x1ffu; nAq = (mo.x >> 21) & 63u; nA = (nAq + 1u) >> 1; nB = mo.x >> 27;
         meta = mo.x & 0xfffu;                    // degree | point-source mask << 8 (the generic layout without the length)
         oid = mo.y;
     }
@@ -537,8 +538,12 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
               // the batch of eight in two halves on the 64-register form: the reads of the second half are not hoisted over the
               // arithmetic of the first
               constexpr int GD_HALF = (TILED && S16 && MODE == GD_MODE_STEP && GD_STEP_WAVES == 8) ? 4 : (int)GD_UNROLL;
+              // the near class is counted in fours: the upper half of its last chunk is padding for a bead with an odd count, and
+              // the threads of a block are ordered by that count -- most waves skip the half batch altogether
+              const bool upper = !(TILED && k0 / GD_UNROLL + 1u == nchA && (nAq & 1u));
 #pragma unroll
               for (int uh = 0; uh < (int)GD_UNROLL; uh += GD_HALF) {
+                if (GD_HALF != (int)GD_UNROLL && uh != 0 && __builtin_amdgcn_ballot_w64(upper) == 0ull) break;
                 if (GD_HALF != (int)GD_UNROLL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = uh; u < uh + GD_HALF; u++) {
@@ -1323,25 +1328,25 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     // trip counts), but writes each bead's list, adjacency chunks and record at the position gt of the k_step thread
     // that will own it.
     if (TILED) {
-        // (two barriers: histogram cleared + descriptor copied | histogram complete; every wave then scans the 32 bins itself.
+        // (two barriers: histogram cleared + descriptor copied | histogram complete; every wave then scans the 64 bins itself.
         // The first barrier also waits for the tile DMAs issued above.)
-        __shared__ unsigned s_hist[32];
-        if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+        __shared__ unsigned s_hist[64];
+        if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
         if (threadIdx.x >= 64 && threadIdx.x - 64 < sizeof(TileDesc) / 4) ((unsigned *)&s_tdesc)[threadIdx.x - 64] = ((const unsigned *)tdp)[threadIdx.x - 64];
-        unsigned bin = 31u;                                        // slots past N: last
-        if (slot < p.N) bin = 30u - min((unsigned)p.len_prev[(size_t)r * p.N + o_pre], 30u);
+        unsigned bin = 63u;                                        // slots past N: last
+        if (slot < p.N) bin = 62u - min((unsigned)p.len_prev[(size_t)r * p.N + o_pre], 62u);
         __syncthreads();
         const unsigned rank = atomicAdd(&s_hist[bin], 1u);
         __syncthreads();
-        unsigned incl = s_hist[lane & 31u];
+        unsigned incl = s_hist[lane];
         const unsigned own = incl;
-        for (int o = 1; o < 32; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)(lane & 31u) >= o) incl += v; }
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
         gt = rbase + blk * GD_BLOCK + (unsigned)__shfl((int)(incl - own), (int)bin, 64) + rank;
     }
     GD_FSTAMP(0);     // staging + barrier
     unsigned cnt = 0;
     if (slot < p.N) {
-        unsigned listlen = 0, nA = 0, nB = 0;
+        unsigned listlen = 0, nAq = 0, nB = 0;
         const unsigned o = p.orig_out[g];
         const unsigned *so = p.slot_of + (size_t)r * p.N;
         const unsigned nr_tile = TILED ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_td.nranges) : 0u;      // (merged ranges in use: three, typically)
@@ -1590,21 +1595,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], class_over ? max(needw, GD_TILED_MAX_W + 1u) : needw);
             }
             listlen = min(found, p.W);
+            nAq = min((cnt + 3u) / 4u, 62u);            // near entries in fours (the record's count; chunks are still written whole)
             while (cnt % GD_UNROLL) push(self);
             flush();
             if (TILED) while (cntB % GD_UNROLL) push_far(self);
             // (an overflowed list is flagged and its chunk rolled back; the chunk counts still have to stay inside the row)
-            nA = min(min(cnt / GD_UNROLL, 31u), NC); nB = min(min(cntB / GD_UNROLL, 31u), NC - nA);
+            nAq = min(nAq, 2u * NC); nB = min(min(cntB / GD_UNROLL, 31u), NC - (nAq + 1u) / 2u);
             cnt = found;
         }
         const unsigned meta = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
         if (TILED) {
             const float4 xb = rpos[slot];
             p.rec_x0[gt] = make_float4(xb.x, xb.y, xb.z, __uint_as_float(slot - blk * GD_BLOCK));
-            // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | near chunks << 21 | far chunks << 26
+            // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | near entries / 4 << 21 | far chunks << 27
             // (at most 31 chunks per class: the host keeps the width of tiled lists <= GD_TILED_MAX_W), bead id (~0: no bead)
-            p.rec_mo[gt] = make_uint2(deg | (((unsigned)p.psmask_o[o] & 0xfu) << 8) | ((slot - blk * GD_BLOCK) << 12) | (nA << 21) | (nB << 26), o);
-            p.len_prev[(size_t)r * p.N + o] = (unsigned char)min(nA, 30u);       // (the near class is what most steps run over)
+            p.rec_mo[gt] = make_uint2(deg | (((unsigned)p.psmask_o[o] & 0xfu) << 8) | ((slot - blk * GD_BLOCK) << 12) | (nAq << 21) | (nB << 27), o);
+            p.len_prev[(size_t)r * p.N + o] = (unsigned char)nAq;       // (the near class is what most steps run over)
         } else p.meta[g] = meta;
     }
     if (TILED && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
@@ -1747,8 +1753,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
     if (TILED) {
         const uint2 mo = p.rec_mo[gt];
         const unsigned local = (mo.x >> 12) & 0x1ffu;
-        nA = (mo.x >> 21) & 31u;
-        valid = mo.y != GD_REC_NOBEAD; slot = blk * GD_BLOCK + (valid ? local : 0u); cnt = (nA + ((mo.x >> 26) & 31u)) * 8u;
+        nA = (((mo.x >> 21) & 63u) + 1u) >> 1;
+        valid = mo.y != GD_REC_NOBEAD; slot = blk * GD_BLOCK + (valid ? local : 0u); cnt = (nA + (mo.x >> 27)) * 8u;
     } else if (valid) cnt = p.meta[rbase + slot] >> 16;
     const float4 *__restrict__ rpos = p.pos + rbase;
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);

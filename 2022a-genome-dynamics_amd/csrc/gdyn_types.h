@@ -26,7 +26,7 @@
 #define GD_TILE_RANGES 9                   // (dz,dy) rows of the 27-cell neighbourhood
 #define GD_XCDS 8
 #define GD_REC_NOBEAD 0xffffffffu          // tiled per-thread record: bead id of a thread without a bead
-#define GD_TILED_MAX_W 496u                 // tiled record: 5-bit chunk counts for the near and the far class (2 x 31 x 8 entries)
+#define GD_TILED_MAX_W 496u                 // tiled record: near entries in fours (6 bits) and far chunks (5 bits), at most 31 chunks of 8 per class
 #define GD_DMAX_STRIDE 32u                  // words between the replicas' displacement maxima: one 128-byte line each
 #define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 
