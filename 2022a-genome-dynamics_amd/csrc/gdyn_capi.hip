@@ -108,12 +108,14 @@ struct gd_system {
     int pcur = 0, ccur = 0;
     uint32_t kernel_path = 0;      // 0 auto, 1 generic, 2 tiled
     bool packed_ab = false, tiled_ok = true, list_tiled = false;
+    bool w_packed = false;         // pos.w of the current positions holds the packed (a,b) factors (set by a build, reset by gd_set_positions / a new topology)
     bool has_inner = false; gd_inner_sphere inner{};
     bool has_softcore_bonds = false;
     uint32_t sw_n = 0; double sw_eps = 0, sw_decay = 1, sw_cut = 0;     // droplet attraction (gd_set_pair_softwell)
     DevBuf<unsigned> sw_targets; DevBuf<double> sw_esum;
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
     uint32_t tile_hold = 0;        // chunks to stay in the larger tile class after an overflow
+    uint32_t last_need_t = 0;      // largest tile of the last build that reported one (entries)
     uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
     uint32_t cpb = 1, tile_cap = 3312;
 
@@ -146,6 +148,8 @@ struct gd_system {
     float rn = 0;                   // near-class radius of the tiled list in use
     double a2_ema = 0;              // running mean of (largest displacement)^2 per step of an interval (interval adaptation; 0: none yet)
     double last_dt = 0, last_kT = -1;
+    int last_flags = 0;             // flags of the last gd_run (the look-ahead of a list built between runs, gd_search_pairs)
+    bool search_list = false;       // the list in use was built by gd_search_pairs at a radius beyond the force list's
     // Skin selection by measured cost (per workload): a few candidate widths are each run for a few verified chunks once the
     // rebuild interval has settled, the device time per step decides (gd_run, tune_skin).  Results do not depend on the skin
     // (verified lists + rollback), only the cost does.
@@ -271,7 +275,7 @@ extern "C" int gd_set_positions(gd_system *s, const double *xyz)
                             (size_t)s->N * sizeof(float4), s->R, hipMemcpyHostToDevice, s->stream));
     gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->list_valid = false; s->state_serial++;
+    s->list_valid = false; s->state_serial++; s->w_packed = false;
     return GD_OK;
 }
 
@@ -636,7 +640,7 @@ static int finalize_topology(gd_system *s)
     s->WB = WBp; s->has_bend = has_bend; s->has_bonds = !all.empty();
     s->mob_uniform = (float)s->mob[0];
     for (uint32_t i = 1; i < N; i++) if ((float)s->mob[i] != s->mob_uniform) { s->mob_uniform = -1.f; break; }
-    s->topo_dirty = false; s->list_valid = false;
+    s->topo_dirty = false; s->list_valid = false; s->w_packed = false;
     return GD_OK;
 }
 
@@ -747,9 +751,11 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.chain = s->chain.p; b.nbr = (with_list && !tiled) ? s->nbr.p : nullptr; b.nbr16 = tiled ? s->nbr16.p : nullptr;
     b.meta = s->meta.p; b.rec_x0 = s->rec_x0.p; b.rec_mo = s->rec_mo.p; b.len_prev = s->len_prev.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
+    b.w_valid = (s->packed_ab && s->w_packed) ? 1 : 0;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
     gd_launch_build(b, s->stream);
     s->list_tiled = tiled; s->list_tile_cap = s->tile_cap;
+    s->w_packed = s->packed_ab;
     s->pcur ^= 1; s->ocur ^= 1;
     s->rv = rv; s->rn = b.rn; s->steps_since_build = 0; s->rebuilds++;
     s->timing.rebuild_launches++;
@@ -790,6 +796,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         over |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] != 0; need_w = std::max(need_w, f[r * GD_NFLAGS + GD_FLAG_NEED_W]);
         tover |= f[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] != 0; need_t = std::max(need_t, f[r * GD_NFLAGS + GD_FLAG_NEED_TILE]);
     }
+    if (need_t > 0 && need_t < (1u << 20)) s->last_need_t = need_t;
     if (!tover && !over && s->list_tiled && need_t > 0) {
         // size the LDS tile to what the builds actually need (more resident blocks per CU)
         // LDS capacity is a step function of the tile size: k_step keeps 3 / 2 / 1 blocks (6 / 4 / 2 waves per SIMD)
@@ -798,17 +805,16 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // keeps the larger class for a while, so the margin for the smaller class can be thin)
         unsigned want = pick_tile_cap(need_t + 24);
         if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
-        if (s->box_kind == GD_BOX_PERIODIC && want > 5072u) { s->tiled_ok = false; s->tiled_off = 1; }      // (see the overflow branch below)
-        else if (want != s->tile_cap && want <= 8192u) {
+        if (want != s->tile_cap && want <= 8192u) {
             if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
         }
     }
     if (tover) {
         const unsigned cap = pick_tile_cap(need_t + need_t / 32 + 32);
-        // 128 KB dynamic + static part < 160 KB of LDS per CU.  Periodic tiles are whole rows of cells and pay the minimum
-        // image per pair: with one resident block per CU they lose to the generic path (measured on S-1kb-250k)
-        const unsigned cap_max = s->box_kind == GD_BOX_PERIODIC ? 5072u : 8192u;
+        // 128 KB dynamic + static part < 160 KB of LDS per CU (one resident block per CU at the largest class: still ahead of the
+        // generic path's global gathers -- S-1kb-250k x 16: 471 us per step generic, 239 us tiled at two blocks per CU)
+        const unsigned cap_max = 8192u;
         if (cap <= cap_max) { s->tile_cap = cap; s->tile_hold = 4; }
         else { s->tiled_ok = false; s->tiled_off = 1; }     // too dense for one tile: generic path (retried later with back-off)
     }
@@ -871,7 +877,7 @@ static int ensure_fresh_list(gd_system *s)
 {
     if (s->list_valid && s->steps_since_build == 0) return GD_OK;
     GDCHK(build_now(s, list_radius(s, nullptr, 0), pair_cutoff(s) > 0));
-    s->list_valid = true;
+    s->list_valid = true; s->search_list = false;
     return GD_OK;
 }
 
@@ -956,6 +962,14 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
         next = best; t.done = true; t.wait = 50; t.K_ref = interval_for_skin(s, t.cand[best]);
     }
     if (t.cand[next] != s->skin) {
+        // the tile class for the new width: tiles scale about with the square of the list radius (rows of cells x their
+        // neighbour rows); sized from the last build's largest tile so that the candidate is not measured in a class it does
+        // not need (or found by overflow and rollback)
+        if (s->last_need_t > 0 && s->rv > 0) {
+            const double cut = pair_cutoff(s), r0 = cut * (1.0 + s->skin), r1 = cut * (1.0 + t.cand[next]);
+            const unsigned est = (unsigned)(1.08 * s->last_need_t * (r1 / r0) * (r1 / r0)) + 32u;
+            s->tile_cap = std::min(pick_tile_cap(est), 8192u); s->tile_hold = 0;
+        }
         s->skin = t.cand[next];
         s->K = interval_for_skin(s, s->skin); s->K_bad_ttl = 0;
         s->list_valid = false;
@@ -984,6 +998,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     GDCHK(apply_pending(s));
     s->state_serial++;
     if (run->timestep != s->last_dt || run->temperature != s->last_kT) { s->a2_ema = 0; s->last_dt = run->timestep; s->last_kT = run->temperature; }   // another regime: measure afresh
+    s->last_flags = run->flags;
     const bool with_list = pair_cutoff(s) > 0;
     const size_t RN = (size_t)s->R * s->N;
     memset(&s->timing, 0, sizeof s->timing);
@@ -1015,6 +1030,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         // snapshot for rollback: positions in bead order + context
         gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->snap.p, s->N, s->Np, s->R, 0, s->stream);
         const std::vector<DevCtx> snap_ctx = s->hctx;
+        const bool snap_w_packed = s->w_packed;      // (the snapshot's w is what the positions carried at this point)
         GDCHK(clear_flags(s));
 
         StepParams p;
@@ -1037,11 +1053,15 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         HIPCHK(hipEventRecord(ev_begin, s->stream));
         int64_t k = 0;
         bool full_interval = false;      // the chunk contains the last step of a complete K-step interval
+        // (an interval that runs on a contact-search list has a wider skin than the force lists: its displacement is no measure
+        // for the interval of those)
+        bool on_search_list = s->list_valid && s->search_list;
         while (k < chunk) {
             if (!s->list_valid || s->steps_since_build >= s->K) {
                 hipEvent_t e0 = get_event(s, nev++), e1 = get_event(s, nev++);
                 HIPCHK(hipEventRecord(e0, s->stream));
                 GDCHK(enqueue_build(s, list_radius(s, run, (uint32_t)(k + s->K)), with_list));
+                s->search_list = false;
                 HIPCHK(hipEventRecord(e1, s->stream));
                 spans.push_back({nev - 2, 1});
                 s->list_valid = true;
@@ -1102,7 +1122,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             HIPCHK(hipMemcpy2DAsync(s->pos[s->pcur].p, (size_t)s->Np * sizeof(float4), s->snap.p, (size_t)s->N * sizeof(float4),
                                     (size_t)s->N * sizeof(float4), s->R, hipMemcpyDeviceToDevice, s->stream));
             gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
-            s->hctx = snap_ctx; s->ctx_dirty = true;
+            s->hctx = snap_ctx; s->ctx_dirty = true; s->w_packed = snap_w_packed;
             GDCHK(upload_ctx(s));
             s->list_valid = false;
             if (violated && !over) {
@@ -1122,7 +1142,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             // try it again at the next build, with the largest tile class; a new overflow costs one rolled-back chunk
             // and doubles the waiting time
             s->tiled_ok = true; s->tiled_off = 0; s->tiled_wait = 0; s->tiled_backoff = std::min(2 * s->tiled_backoff, 1024u);
-            s->tile_cap = s->box_kind == GD_BOX_PERIODIC ? 5072u : 8192u;
+            s->tile_cap = 8192u;
         }
         float ms = 0;
         for (auto &sp : spans) {
@@ -1135,7 +1155,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         unsigned long long L = 0;
         for (auto v : s->lcount) L += v;
         s->timing.list_entries_visited += L * (uint64_t)chunk;   // L of the last build, per step
-        if (s->adapt && with_list && full_interval) {
+        if (s->adapt && with_list && full_interval && !on_search_list) {
             const double cut_now = pair_cutoff(s) * (s->pair.scale_by_bead_scale ? bead_scale_bound(s, nullptr, 0) : 1.0);
             const double lim = 0.5 * (s->rv - cut_now), d = std::sqrt((double)maxd2);
             if (lim > 0 && d > 0) {
@@ -1227,9 +1247,14 @@ extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *
         bool done = false;
         for (int attempt = 0; attempt < 6 && !done; attempt++) {
             if (!s->list_valid || !((float)dcut <= s->rv) || s->list_W == 0) {
-                const float rv_force = with_list ? list_radius(s, nullptr, 0) : 0.f;
-                GDCHK(build_now(s, std::max(rv_force, (float)(dcut * (1.0 + 1e-6))), true));
-                s->list_valid = true;
+                // the list stays in use as the force list of the next run: built with that run's look-ahead (a growing bead
+                // scale over the rest of an interval), like the builds inside gd_run
+                gd_run_desc ahead{};
+                ahead.timestep = s->last_dt; ahead.flags = s->last_flags;
+                const float rv_force = with_list ? list_radius(s, s->last_dt > 0 ? &ahead : nullptr, s->K) : 0.f;
+                const float rv_search = (float)(dcut * (1.0 + 1e-6));
+                GDCHK(build_now(s, std::max(rv_force, rv_search), true));
+                s->list_valid = true; s->search_list = rv_search > rv_force;
             }
             const double lim = 0.5 * ((double)s->rv - dcut);
             PairsP q;

@@ -1147,8 +1147,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
     const unsigned ns = p.cell_start[(size_t)r * (p.ncell_cap + 1) + c] + p.rank[g];
     const unsigned o = p.orig_in[g];
     float4 x = p.pos_in[g];
-    const float2 ab = p.ab_o[o];
-    if (p.packed_ab) x.w = pack_ab(ab);
+    // (a,b) ride in pos.w and every kernel carries w along: only positions that came from the host (w = 0) need the per-bead
+    // gather again
+    float2 ab = make_float2(0.f, 0.f);
+    if (!p.packed_ab || !p.w_valid) ab = p.ab_o[o];
+    if (p.packed_ab && !p.w_valid) x.w = pack_ab(ab);
     const size_t gn = rbase + ns;
     p.pos_out[gn] = x;
     if (!p.tiled) p.xb[gn] = x;      // build positions by slot: the generic path's skin check (the tiled path keeps them per thread, rec_x0)

@@ -233,6 +233,7 @@ struct BuildParams {
     unsigned *cell_s;                   // cell of each new slot
     unsigned W;
     int tiled, packed_ab;
+    int w_valid;                        // pos_in.w already holds the packed (a,b) (written by an earlier build, kept by every step)
     unsigned cpb, tile_cap;
     unsigned *flags;
     unsigned long long *lcount;         // [R] directed list entries

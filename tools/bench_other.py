@@ -11,6 +11,7 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 skin = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 path = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+relax = int(sys.argv[6]) if len(sys.argv) > 6 else max(steps // 2, 100)      # (long enough for the skin sweep: ~5000 for the 1 kb model)
 if which == "1kb":
     s, info = wl.chromatin_1kb(hip, n_beads=250000, n_replicas=R); flags = 0
 elif which == "spindle":
@@ -22,7 +23,7 @@ elif which == "abbox":
 dt, kT = info["timestep"], info["temperature"]
 if skin > 0 or path: s.set_tuning(skin=skin, kernel_path=path)
 s.begin_phase()
-s.run(max(steps // 2, 100), dt, kT, seed=5, flags=0)
+s.run(relax, dt, kT, seed=5, flags=0)
 s.begin_phase()
 s.run(100, dt, kT, seed=6, flags=flags)
 t0 = time.perf_counter(); tm = s.run(steps, dt, kT, seed=7, flags=flags); el = time.perf_counter() - t0

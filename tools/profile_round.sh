@@ -1,18 +1,28 @@
 #!/bin/bash
 # tools/profile_round.sh <tag>: the round's evidence in one GPU call -- relaxed state, rocprofv3 kernel stats, PMC passes
-# (separate, no tracing domains), plain bench lines.  Everything lands in gpurun_out/<tag>_*; copy what is judged to profiles/.
-tag=${1:-r02}
+# (separate, no tracing domains), plain bench lines; then the same for S-1kb-250k x 16.  Everything lands in gpurun_out/<tag>_*;
+# copy what is judged to profiles/ (tools/traffic_json.py writes profiles/<tag>_traffic*.json).
+# The runs from the saved state pin the list width (--skin 0.75, the value the sweep settles on for this workload: its log line is
+# in <tag>_bench.err) so that no sweep candidate runs inside the profiled window.
+tag=${1:-r03}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 python3 $root/bench.py --save-state /tmp/state.npy > /dev/null 2>&1
 echo "[profile] state saved"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $root/bench.py --load-state /tmp/state.npy --warmup 300 --steps 1000 --no-cpu-baseline --no-extra > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $root/bench.py --skin 0.75 --load-state /tmp/state.npy --warmup 300 --steps 1000 --no-cpu-baseline --no-extra > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_bench_under_rocprof.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
 python3 $root/tools/kstats.py /tmp/prof_stats > $out/${tag}_bench_kernel_stats.txt
 echo "[profile] kernel stats done"
-PMC_SCRIPT=bench.py bash $root/tools/pmc.sh $tag --load-state /tmp/state.npy --warmup 200 --steps 200 --no-cpu-baseline --no-extra
+PMC_SCRIPT=bench.py bash $root/tools/pmc.sh $tag --skin 0.75 --load-state /tmp/state.npy --warmup 200 --steps 200 --no-cpu-baseline --no-extra
 cp $out/pmc_$tag/summary.txt $out/${tag}_bench_pmc_summary.txt
 echo "[profile] pmc done"
+# ---- S-1kb-250k x 16 (periodic, tiled rows): kernel stats + the traffic counters
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_1kb -- python3 $root/tools/bench_other.py 1kb 16 600 0 0 5000 > $out/${tag}_1kb_bench_under_rocprof.json 2> $out/${tag}_1kb_bench_under_rocprof.err
+cp $(find /tmp/prof_stats_1kb -name "*kernel_stats.csv" | head -1) $out/${tag}_1kb_bench_kernel_stats.csv
+python3 $root/tools/kstats.py /tmp/prof_stats_1kb > $out/${tag}_1kb_bench_kernel_stats.txt
+PMC_SETS_ONLY="FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" PMC_SCRIPT=tools/bench_other.py bash $root/tools/pmc.sh ${tag}_1kb 1kb 16 600 0 0 5000
+cp $out/pmc_${tag}_1kb/summary.txt $out/${tag}_1kb_bench_pmc_summary.txt
+echo "[profile] 1kb done"
 cd $root
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "[profile] driver-line bench done"
