@@ -77,7 +77,8 @@ class _RunDesc(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("skin", C.c_double), ("rebuild_interval", C.c_uint32), ("adapt_interval", C.c_uint32),
-                ("list_width", C.c_uint32), ("kernel_path", C.c_uint32), ("near_fraction", C.c_double)]
+                ("list_width", C.c_uint32), ("kernel_path", C.c_uint32), ("near_fraction", C.c_double),
+                ("auto_skin", C.c_uint32)]
 
 
 class Timing(C.Structure):
@@ -353,8 +354,8 @@ class System:
             self.lib.check(self.lib.dll.gd_search_pairs(self._h, replica, dcut, _uptr(out), n.value, C.byref(n)))
         return out
 
-    def set_tuning(self, skin=0.0, rebuild_interval=0, adapt_interval=1, list_width=0, kernel_path=0, near_fraction=0.0):
-        t = Tuning(skin, rebuild_interval, adapt_interval, list_width, kernel_path, near_fraction)
+    def set_tuning(self, skin=0.0, rebuild_interval=0, adapt_interval=1, list_width=0, kernel_path=0, near_fraction=0.0, auto_skin=0):
+        t = Tuning(skin, rebuild_interval, adapt_interval, list_width, kernel_path, near_fraction, auto_skin)
         self.lib.check(self.lib.dll.gd_set_tuning(self._h, C.byref(t)))
 
     def timing(self):

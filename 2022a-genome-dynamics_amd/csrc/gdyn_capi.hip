@@ -154,7 +154,7 @@ struct gd_system {
     // rebuild interval has settled, the device time per step decides (gd_run, tune_skin).  Results do not depend on the skin
     // (verified lists + rollback), only the cost does.
     struct SkinTuner {
-        bool enabled = true, done = false;
+        bool enabled = false, done = false;     // opt-in: gd_tuning.auto_skin
         std::vector<double> cand, cost;
         size_t idx = 0;
         int settle = 0, measured = 0, wait = 4, rounds = 0;      // wait: accepted chunks before the (next) sweep may start
@@ -205,8 +205,8 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
     s->lcount.assign(s->R, 0ull);
     s->ncell_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8ull * s->N, 4096ull), 262144ull);
     if (const char *e = dev_env("GDYN_NEAR_FRAC")) s->near_frac = atof(e);
-    if (const char *e = dev_env("GDYN_SKIN")) { s->skin = atof(e); s->tuner.enabled = false; }
-    if (dev_env("GDYN_NO_SKIN_TUNER")) s->tuner.enabled = false;
+    if (const char *e = dev_env("GDYN_SKIN")) s->skin = atof(e);
+    if (dev_env("GDYN_AUTO_SKIN")) s->tuner.enabled = true;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(GD_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     const size_t RNp = (size_t)s->R * s->Np, RN = (size_t)s->R * s->N;
@@ -527,9 +527,10 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
     if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");      // (validated before any state changes)
     if (t->near_fraction < 0 || t->near_fraction > 1) return fail(GD_EINVAL, "gd_set_tuning: near_fraction must be in [0,1]");
-    if (t->skin > 0) { s->skin = t->skin; s->tuner.enabled = false; }      // an explicit width is kept
+    if (t->skin > 0) s->skin = t->skin;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
-    if (!t->adapt_interval) s->tuner.enabled = false;                        // a fixed cadence: nothing to select for
+    s->tuner = gd_system::SkinTuner{};
+    s->tuner.enabled = t->auto_skin != 0 && t->adapt_interval != 0;          // (a fixed cadence: nothing to select for)
     if (t->near_fraction > 0) s->near_frac = t->near_fraction;
     s->a2_ema = 0;
     s->adapt = t->adapt_interval;

@@ -117,6 +117,11 @@ private:
         desc.n_beads = (uint32_t)_n; desc.n_replicas = 1; desc.device = device; desc.box_kind = GD_BOX_PERIODIC;
         desc.box[0] = desc.box[1] = desc.box[2] = ch.box_size;
         chk(gd_create(&desc, &_sys));
+        {   // the list width for this model's density and cutoff: selected by the library from measured chunk times
+            gd_tuning tune{};
+            tune.adapt_interval = 1; tune.auto_skin = 1;
+            chk(gd_set_tuning(_sys, &tune));
+        }
         std::vector<double> mobility(_n, ch.monomer_mobility), bending(_n, ch.bending_energy);
         for (auto const &c : _chains)
             for (auto const &block : c.config->blocks)

@@ -138,8 +138,10 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
     clock as the headline (wall time of gd_run): ms per step, bead-steps/s, rollbacks.  Reported under config.other_workloads."""
     out = []
 
-    def run_one(tag, make, flags, relax, steps):
+    def run_one(tag, make, flags, relax, steps, tune=None):
         s, info = make()
+        if tune:
+            s.set_tuning(**tune)
         dt, kT = info["timestep"], info["temperature"]
         N, R = info["n_beads"], s.R
         s.begin_phase()
@@ -167,17 +169,18 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
     f3 = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
     run_one("S-genome-30k x 1 replica (what one reference-shaped driver process runs)",
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=1, device=dev_index), f3, 4000, 2 * budget_steps)
-    run_one("S-genome-62k x 64 replicas (production bead count; as many beads per launch as the headline)",
-            lambda: wl.genome_interphase(hip, n_beads=62178, n_replicas=64, device=dev_index), f3, 4000, budget_steps)
+    run_one("S-genome-62k x 32 replicas (production bead count)",
+            lambda: wl.genome_interphase(hip, n_beads=62178, n_replicas=32, device=dev_index), f3, 4000, budget_steps)
     run_one("S-genome-30k x 128, bead_scale_init 0.5 (time-varying cutoff, simulation_driver_forcefield.cc:47-49)",
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, bead_scale_init=0.5, device=dev_index), f3, 4000, budget_steps)
     run_one("S-genome-30k x 128, 2nd-bond spring 0 (variant of SURVEY 8d)",
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, second_bond_spring=0.0, device=dev_index), f3, 4000, budget_steps)
-    # (the list width is selected per workload from measured chunk times: the relaxation is long enough for that sweep)
-    run_one("S-1kb-250k x 4 replicas (periodic, loops + glues static)",
-            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=4, device=dev_index), 0, 5000, budget_steps)
-    run_one("S-1kb-250k x 16 replicas (as many beads per launch as the headline)",
-            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=16, device=dev_index), 0, 5000, budget_steps)
+    # (gd_tuning.auto_skin: the list width is selected for the workload from measured chunk times; the relaxation is long enough
+    # for that sweep.  The genome workloads run at the library default, 0.75, which their sweeps confirm.)
+    run_one("S-1kb-250k x 4 replicas (periodic, loops + glues static; auto_skin)",
+            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=4, device=dev_index), 0, 5000, budget_steps, tune=dict(auto_skin=1))
+    run_one("S-1kb-250k x 16 replicas (as many beads per launch as the headline; auto_skin)",
+            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=16, device=dev_index), 0, 5000, budget_steps, tune=dict(auto_skin=1))
     return out
 
 

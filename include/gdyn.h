@@ -306,6 +306,10 @@ typedef struct {
                                    that every step walks, the rest in a "far" class that is walked only once displacements
                                    make it matter (results do not depend on it beyond summation order); 0 keeps the current
                                    value (default 0.65); a value near 0 makes every step walk both classes */
+    uint32_t auto_skin;         /* 1: select the skin for this workload from measured chunk times (a few candidate widths, each run
+                                   for a few verified chunks once the rebuild interval has settled; repeated when the interval
+                                   drifts).  Costs a few thousand steps at candidate widths; results are independent of the skin
+                                   (verified lists), so only the cost changes.  0 (default): keep `skin` */
 } gd_tuning;
 
 int gd_set_tuning(gd_system *sys, const gd_tuning *t);

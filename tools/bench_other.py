@@ -21,7 +21,7 @@ elif which == "genome62k":
 elif which == "abbox":
     s, info = wl.ab_box(hip, n_replicas=R); flags = 0
 dt, kT = info["timestep"], info["temperature"]
-if skin > 0 or path: s.set_tuning(skin=skin, kernel_path=path)
+s.set_tuning(skin=skin, kernel_path=path, auto_skin=0 if skin > 0 else int(os.environ.get("AUTO_SKIN", "1" if which == "1kb" else "0")))
 s.begin_phase()
 s.run(relax, dt, kT, seed=5, flags=0)
 s.begin_phase()

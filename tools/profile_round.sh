@@ -2,18 +2,16 @@
 # tools/profile_round.sh <tag>: the round's evidence in one GPU call -- relaxed state, rocprofv3 kernel stats, PMC passes
 # (separate, no tracing domains), plain bench lines; then the same for S-1kb-250k x 16.  Everything lands in gpurun_out/<tag>_*;
 # copy what is judged to profiles/ (tools/traffic_json.py writes profiles/<tag>_traffic*.json).
-# The runs from the saved state pin the list width (--skin 0.75, the value the sweep settles on for this workload: its log line is
-# in <tag>_bench.err) so that no sweep candidate runs inside the profiled window.
 tag=${1:-r03}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 python3 $root/bench.py --save-state /tmp/state.npy > /dev/null 2>&1
 echo "[profile] state saved"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $root/bench.py --skin 0.75 --load-state /tmp/state.npy --warmup 300 --steps 1000 --no-cpu-baseline --no-extra > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $root/bench.py --load-state /tmp/state.npy --warmup 300 --steps 1000 --no-cpu-baseline --no-extra > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_bench_under_rocprof.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
 python3 $root/tools/kstats.py /tmp/prof_stats > $out/${tag}_bench_kernel_stats.txt
 echo "[profile] kernel stats done"
-PMC_SCRIPT=bench.py bash $root/tools/pmc.sh $tag --skin 0.75 --load-state /tmp/state.npy --warmup 200 --steps 200 --no-cpu-baseline --no-extra
+PMC_SCRIPT=bench.py bash $root/tools/pmc.sh $tag --load-state /tmp/state.npy --warmup 200 --steps 200 --no-cpu-baseline --no-extra
 cp $out/pmc_$tag/summary.txt $out/${tag}_bench_pmc_summary.txt
 echo "[profile] pmc done"
 # ---- S-1kb-250k x 16 (periodic, tiled rows): kernel stats + the traffic counters
