@@ -111,6 +111,7 @@ struct gd_system {
     bool w_packed = false;         // pos.w of the current positions holds the packed (a,b) factors (set by a build, reset by gd_set_positions / a new topology)
     bool has_inner = false; gd_inner_sphere inner{};
     bool has_softcore_bonds = false;
+    bool bonds_premixed = false;   // every bond parameter record is unmixed (AB mixing resolved per bond by finalize_topology)
     uint32_t sw_n = 0; double sw_eps = 0, sw_decay = 1, sw_cut = 0;     // droplet attraction (gd_set_pair_softwell)
     DevBuf<unsigned> sw_targets; DevBuf<double> sw_esum;
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
@@ -571,6 +572,33 @@ static int finalize_topology(gd_system *s)
         const int t = (int)types.size() - 1;
         for (size_t k = 0; k + 1 < s->dyn[d].pairs.size(); k += 2) all.push_back({s->dyn[d].pairs[k], s->dyn[d].pairs[k + 1], t});
     }
+    // AB-mixed bond sets (K = a Ka + b Kb, l = a la + b lb with a = (a_i + a_j)/2, b likewise: simulation_driver_forcefield.cc:58-88)
+    // have few distinct (a, b) per set -- the bead types are a handful of values -- so every bond gets the index of its own,
+    // already mixed, parameter record and the kernels skip the per-bond mixing arithmetic.  More records than the table holds:
+    // the sets stay as given and the kernels mix at run time.
+    s->bonds_premixed = false;
+    {
+        std::vector<gd_bond_params> t2; std::vector<int> term2; std::vector<Bond> all2 = all;
+        bool fits = true, any_mixed = false;
+        for (auto &b : all2) {
+            gd_bond_params q = types[b.type];
+            if (q.mix) {
+                any_mixed = true;
+                const double a = 0.5 * (s->a[b.i] + s->a[b.j]), bb = 0.5 * (s->b[b.i] + s->b[b.j]);
+                q.k_a = a * q.k_a + bb * q.k_b; q.l_a = a * q.l_a + bb * q.l_b; q.k_b = 0; q.l_b = 0; q.mix = 0;
+            }
+            int found = -1;
+            for (size_t k = 0; k < t2.size() && found < 0; k++)
+                if (!memcmp(&t2[k], &q, sizeof q) && term2[k] == terms[b.type]) found = (int)k;
+            if (found < 0) {
+                if (t2.size() >= GD_MAX_BOND_TYPES) { fits = false; break; }
+                t2.push_back(q); term2.push_back(terms[b.type]); found = (int)t2.size() - 1;
+            }
+            b.type = found;
+        }
+        if (fits && any_mixed) { types.swap(t2); terms.swap(term2); all.swap(all2); s->bonds_premixed = true; }
+        else if (!any_mixed) s->bonds_premixed = true;      // nothing to mix at run time either way
+    }
     std::vector<unsigned> deg(N, 0);
     for (auto &b : all) { deg[b.i]++; deg[b.j]++; }
     uint32_t WB = 0;
@@ -701,6 +729,7 @@ static void fill_common(gd_system *s, StepParams &p)
     }
     p.scaling = ScaleP{s->has_scaling ? 1 : 0, 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau, 0.0, 0.0};
     p.btab = s->btab.p; p.nbt = (int)s->n_bond_types; p.has_softcore_bonds = s->has_softcore_bonds ? 1 : 0;
+    p.bonds_premixed = s->bonds_premixed ? 1 : 0;
     p.nps = (int)s->psrc.size();
     for (int q = 0; q < p.nps; q++) {
         p.ps[q].kind = s->psrc[q].kind; p.ps[q].k = (float)s->psrc[q].k; p.ps[q].b = (float)s->psrc[q].b;

@@ -629,11 +629,15 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                             float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
                             if (PERIODIC && (flags & 4u)) d = min_image(d, p.box, p.inv_box);
                             const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                            const float2 abj = unpack_ab(xj.w);
-                            const bool mixed = (flags & 1u) != 0u, scaled = (flags & 2u) != 0u;
-                            const float a = mixed ? 0.5f * (abi.x + abj.x) : 1.0f, b = mixed ? 0.5f * (abi.y + abj.y) : 0.0f;
-                            const float K = (a * ta[u].x + b * ta[u].y) * (scaled ? inv_bs2 : 1.0f);
-                            const float l = (a * ta[u].z + b * ta[u].w) * (scaled ? s_ctx.bond_scale : 1.0f);
+                            const bool scaled = (flags & 2u) != 0u;
+                            float K = ta[u].x, l = ta[u].z;
+                            if (!p.bonds_premixed) {      // (uniform: the host could not resolve the AB mixing per bond)
+                                const float2 abj = unpack_ab(xj.w);
+                                const bool mixed = (flags & 1u) != 0u;
+                                const float a = mixed ? 0.5f * (abi.x + abj.x) : 1.0f, b = mixed ? 0.5f * (abi.y + abj.y) : 0.0f;
+                                K = a * ta[u].x + b * ta[u].y; l = a * ta[u].z + b * ta[u].w;
+                            }
+                            K *= scaled ? inv_bs2 : 1.0f; l *= scaled ? s_ctx.bond_scale : 1.0f;
                             // harmonic / spring / semispring in one form: elongation x = r - l clamped from below
                             const float inv_d = r2 > 0.0f ? __builtin_amdgcn_rsqf(r2) : 0.0f;     // hardware rsq, 1 ulp
                             const float x = fmaxf(fmaf(r2, inv_d, -l), tb[u].y);
