@@ -781,3 +781,25 @@ def test_full_size_noisy_trajectories(hip, oracle, n_beads):
         d -= L * np.rint(d / L)              # a bead within rounding of the box face may be wrapped on one side only
     assert np.abs(d).max() <= POS_ATOL_20STEP * max(1.0, np.abs(xo).max() / 8)
     assert sh.context().step == so.context().step == 5
+
+
+def test_auto_skin_sweep_keeps_results_and_settles(hip, oracle):
+    """gd_tuning.auto_skin: the list width is selected from measured chunk times while the run goes on (candidate widths, each
+    for a few verified chunks).  Whatever it selects, the lists are verified: after the sweep the forces on the current positions
+    equal the oracle's, the list radius is one of the candidates', and the sweep itself rolled back at most a chunk per candidate."""
+    R = 8
+    s, info = wl.genome_interphase(hip, n_beads=6000, n_replicas=R)
+    s.set_tuning(auto_skin=1)
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    s.begin_phase()
+    s.run(6000, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+    c = s.context()
+    cut = 0.30
+    assert any(abs(c.list_radius - cut * (1 + 0.75 * f)) < 1e-3 for f in (1.0, 0.7, 0.5, 0.35, 1.4 * 0.7, 1.4 * 0.5, 0.49, 0.35 * 0.7)), c.list_radius
+    assert c.rollbacks <= 8 and c.step == 6000
+    so, _ = wl.genome_interphase(oracle, n_beads=6000, n_replicas=1)
+    so.set_positions(s.positions()[3][None])
+    c3 = s.context(3)
+    so.set_context(0, c3.step, c3.bead_scale, c3.bond_scale, tuple(c3.semiaxes))
+    Fo = so.forces()
+    assert np.abs(s.forces()[3] - Fo[0]).max() <= FORCE_RTOL * np.abs(Fo).max()
