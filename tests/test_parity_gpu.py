@@ -803,3 +803,35 @@ def test_auto_skin_sweep_keeps_results_and_settles(hip, oracle):
     so.set_context(0, c3.step, c3.bead_scale, c3.bond_scale, tuple(c3.semiaxes))
     Fo = so.forces()
     assert np.abs(s.forces()[3] - Fo[0]).max() <= FORCE_RTOL * np.abs(Fo).max()
+
+
+@pytest.mark.parametrize("path", ["generic", "tiled"])
+def test_mixed_bond_sets_beyond_the_premixed_table(hip, oracle, path):
+    """AB-mixed bond sets (K = a Ka + b Kb, l = a la + b lb, simulation_driver_forcefield.cc:58-88) are resolved per bond on the
+    host while the distinct (set, a, b) combinations fit the 16-entry table; with many distinct A/B factors they do not, and the
+    kernels mix at run time.  Both against the oracle: 9 distinct factor values (fp16-exact) -> dozens of combinations."""
+    rng = np.random.default_rng(21)
+    n = 1200
+    vals = np.arange(9) / 8.0
+    a, b = rng.choice(vals, n), rng.choice(vals, n)
+    x = np.cumsum(rng.normal(scale=0.12, size=(n, 3)), axis=0)
+    x -= x.mean(axis=0)
+    out = []
+    for lib in (hip, oracle):
+        s = g.System(lib, n, 1)
+        s.set_bead_params(a=a, b=b)
+        s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
+        s.add_bond_range(g.System.bond_params(g.POT_SEMISPRING, k_a=70.0, k_b=40.0, l_a=0.2, l_b=0.25, mix=True), 0, n, 1)
+        s.add_bond_range(g.System.bond_params(g.POT_HARMONIC, k_a=5.0, k_b=3.0, mix=True), 0, n, 2)
+        if lib is hip:
+            s.set_tuning(kernel_path=PATHS[path])
+        s.set_positions(x)
+        out.append((s.forces(), s.forces(g.TERM_BOND), s.energy(g.TERM_BOND)[0], s.context().list_path))
+        s.run(5, 1e-5, 1.0, seed=SEED)
+        out[-1] += (s.positions(),)
+    (Fh, Fbh, Ebh, ph, xh), (Fo, Fbo, Ebo, _, xo) = out
+    scale = np.abs(Fo).max()
+    assert ph == PATHS[path]
+    assert np.abs(Fh - Fo).max() <= FORCE_RTOL * scale and np.abs(Fbh - Fbo).max() <= FORCE_RTOL * scale
+    assert abs(Ebh - Ebo) <= 3 * ENERGY_RTOL * abs(Ebo)
+    assert np.abs(xh - xo).max() <= POS_ATOL_20STEP
