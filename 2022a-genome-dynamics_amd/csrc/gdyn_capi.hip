@@ -954,10 +954,10 @@ static uint32_t interval_for_skin(const gd_system *s, double skin)
     return (uint32_t)std::max(1.0, std::min(200.0, std::floor(k)));
 }
 
-// One accepted chunk of `steps` steps took `ms` on the device.  Candidates: the width in use and 0.7 / 0.5 / 0.35 of it (shorter
-// lists and smaller LDS tiles against more frequent builds; a periodic box whose tiles did not fit may fit them at a smaller
-// width).  Each candidate: one chunk to settle (tile class, list width, interval), three measured.  The width the sweep
-// started from is left only for a gain of 8 % or more (chunk times scatter by a few per cent).
+// One accepted chunk of `steps` steps took `ms` on the device.  Candidates: the width in use, 1.2 x it (fewer builds: what a small
+// launch-latency-bound system wants) and 0.7 / 0.5 / 0.35 of it (shorter lists and smaller LDS tiles against more frequent builds;
+// a periodic box whose tiles did not fit may fit them at a smaller width).  Each candidate: one chunk to settle (tile class, list width, interval), three measured.  The width the sweep
+// started from is left only for a gain of 6 % or more (chunk times scatter by a few per cent).
 static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval, bool rolled_back)
 {
     auto &t = s->tuner;
@@ -973,7 +973,7 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
     }
     if (t.cand.empty()) {
         if (t.wait > 0 && t.rounds == 0) { t.wait--; return; }
-        if (t.rounds == 0) t.cand = {s->skin, 0.7 * s->skin, 0.5 * s->skin, 0.35 * s->skin};
+        if (t.rounds == 0) t.cand = {s->skin, std::min(1.2 * s->skin, 1.0), 0.7 * s->skin, 0.5 * s->skin, 0.35 * s->skin};
         else t.cand = {s->skin, std::min(1.4 * s->skin, 1.0), 0.7 * s->skin};
         t.cost.assign(t.cand.size(), 0.0);
         t.idx = 0; t.settle = 0; t.measured = 0; t.acc_ms = 0; t.acc_steps = 0; t.rounds++;
@@ -986,9 +986,9 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
                                        s->list_tiled ? "tiled" : "generic", s->list_W, s->list_tile_cap);
     size_t next = t.idx + 1;
     while (next < t.cand.size() && (t.cand[next] == s->skin || interval_for_skin(s, t.cand[next]) < 2)) next++;
-    if (next >= t.cand.size()) {      // sweep complete: the cheapest, but the width the sweep started from unless the gain is 8 % or more
+    if (next >= t.cand.size()) {      // sweep complete: the cheapest, but the width the sweep started from unless the gain is 6 % or more
         size_t best = 0;
-        for (size_t k = 1; k < t.cand.size(); k++) if (t.cost[k] > 0 && t.cost[k] < 0.92 * t.cost[0] && t.cost[k] < t.cost[best]) best = k;
+        for (size_t k = 1; k < t.cand.size(); k++) if (t.cost[k] > 0 && t.cost[k] < 0.94 * t.cost[0] && t.cost[k] < t.cost[best]) best = k;
         next = best; t.done = true; t.wait = 50; t.K_ref = interval_for_skin(s, t.cand[best]);
     }
     if (t.cand[next] != s->skin) {
