@@ -10,7 +10,9 @@
  * vectors for it.  This file therefore restates micromd's
  * published potential formulas and follows the reference's own call sites for the
  * parameterisation and sequencing; it is pinned only by analytic known-answer tests,
- * finite differences and the Random123 Philox known-answer vectors (tests/).
+ * finite differences and the Random123 Philox known-answer vectors (tests/).  One piece IS checked against
+ * reference-held code: the ellipsoid wall's nearest-surface construction, against outputs of the reference's own
+ * 5-sim-genome/src/analyze_lamina/geometry.py recorded here (tests/golden/make_wall_fixtures.py).
  *
  * It exports the same C-ABI as include/gdyn.h so the same test code drives both sides.
  * Reference citations are relative to the reference root.

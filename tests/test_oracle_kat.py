@@ -393,3 +393,42 @@ def test_deferred_callback_is_the_reference_observation_point(oracle):
         s2.run(5, dt, kT, seed=4, flags=flags)
         assert np.array_equal(s1.positions(), s2.positions())
         assert tuple(s1.context().semiaxes) == tuple(s2.context().semiaxes) and s2.context().step == 10
+
+
+def test_wall_distance_matches_the_reference_geometry_module(oracle):
+    """Row a9, the nearest-surface construction of the ellipsoid wall: the oracle restates the author's second-order distance
+    (5-sim-genome/src/analyze_lamina/geometry.py:13-28).  Fixtures recorded by IMPORTING that module here
+    (tests/golden/make_wall_fixtures.py): distances of 360 points from three ellipsoids.  The oracle's displacement from the
+    surface is read back through the ABI -- outside the wall the force is -k x displacement (harmonic, k = 1), inside it the
+    soft-core energy eps (1 - r^2/s^2)^3 inverts to r.  The module regularises its quadratic with a + 1e-6 (EPSILON, :4,24);
+    the comparison allows exactly that."""
+    import os
+    from conftest import ROOT
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "wall_distance_fixtures.npz"))
+    eps, sigma = 2.0, 0.6                               # the wall acts at half the diameter: s = 0.3
+    for k in range(3):
+        semi, pts, ref = fx[f"semi{k}"], fx[f"points{k}"], fx[f"dist{k}"]
+        n = len(pts)
+        s = g.System(oracle, n, 1)
+        s.set_bead_params(a=np.ones(n), b=np.zeros(n))
+        s.set_ellipsoid_wall(eps, sigma, 0.0, sigma, 1.0, 0.0, 1.0, (1.0, 1.0, 1.0), 1e-4, tuple(semi), scale_by_bead_scale=False)
+        s.set_positions(pts)
+        F = s.forces(g.TERM_WALL)[0]
+        inv2 = semi ** -2.0
+        a = ((inv2 ** 3)[None, :] * pts * pts).sum(axis=1)          # the `a` of the module's quadratic (its EPSILON acts on it)
+        inside = (pts * pts * inv2[None, :]).sum(axis=1) < 1.0
+        d_out = np.linalg.norm(F, axis=1)                            # |F| = k |displacement|, k = 1
+        assert np.allclose(d_out[~inside] * (a / (a + 1e-6))[~inside], ref[~inside], rtol=1e-9, atol=1e-12)
+        # inside: one bead at a time through the energy (U = eps (1 - r^2 / s^2)^3 for r < s)
+        hs = 0.5 * sigma
+        checked = 0
+        for i in np.nonzero(inside & (ref < 0.9 * hs))[0][:25]:
+            s1 = g.System(oracle, 1, 1)
+            s1.set_bead_params(a=np.ones(1), b=np.zeros(1))
+            s1.set_ellipsoid_wall(eps, sigma, 0.0, sigma, 1.0, 0.0, 1.0, (1.0, 1.0, 1.0), 1e-4, tuple(semi), scale_by_bead_scale=False)
+            s1.set_positions(pts[i][None, None])
+            U = s1.energy(g.TERM_WALL)[0]
+            r = hs * np.sqrt(1.0 - (U / eps) ** (1.0 / 3.0))
+            assert r * a[i] / (a[i] + 1e-6) == pytest.approx(ref[i], rel=1e-7, abs=1e-10), (k, i)
+            checked += 1
+        assert checked >= 5 and (~inside).sum() >= 50
