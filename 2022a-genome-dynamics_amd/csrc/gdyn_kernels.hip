@@ -520,13 +520,17 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             const unsigned self_e = TILED ? (S16 ? (own_base + local) << 4 : own_base + local) : 0u;     // the padding entries (energy mode skips them)
             // software pipeline: the chunk(s) of the next batch are in flight while one is processed
             // (a second batch of look-ahead bought nothing and costs the registers of one occupancy step)
-            if (TILED && nchA == 0u && nch != 0u) qa = nt_load(&lst[(size_t)(NCL - 1u) * 64]);      // (no near chunk: the first one is a far chunk)
+            // (tiled: chunk c of the thread = wave base + c KiB + lane x 16 bytes -- a scalar base and a 32-bit offset, no per-lane
+            // 64-bit pointer lives across the loop)
+            const char *lst_w = (const char *)((const uint4 *)p.nbr16 + gw6 * NCL * 64);
+            auto chunk = [&](unsigned c) -> uint4 { return nt_load((const uint4 *)(lst_w + (c * 1024u + lane * 16u))); };
+            if (TILED && nchA == 0u && nch != 0u) qa = chunk(NCL - 1u);      // (no near chunk: the first one is a far chunk)
             for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
                 unsigned jj[GD_UNROLL];
                 float4 xjv[GD_UNROLL];
                 const uint4 q = qa, q0 = qa, q1 = qb;
                 if (k0 + GD_UNROLL < cntp) {
-                    if (TILED) { const unsigned c1 = k0 / 8 + 1; qa = nt_load(&lst[(size_t)(c1 < nchA ? c1 : NCL - 1u - (c1 - nchA)) * 64]); }
+                    if (TILED) { const unsigned c1 = k0 / 8 + 1; qa = chunk(c1 < nchA ? c1 : NCL - 1u - (c1 - nchA)); }
                     else { qa = lst[(size_t)(k0 / 4 + 2) * 64]; qb = lst[(size_t)(k0 / 4 + 3) * 64]; }
                 }
                 if (TILED) {
@@ -597,7 +601,8 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                 // outside the tile are a rare, wave-uniform detour through global memory.
                 const unsigned own_idx = own_base + local;
                 for (unsigned k0 = 0; k0 < deg; k0 += 4) {
-                    const uint4 aq = k0 == 0 ? adj0 : adj[(size_t)(k0 >> 2) * 64];
+                    // (chunks beyond the first -- a bead with more than four bonds -- by scalar base + 32-bit lane offset, like the lists)
+                    const uint4 aq = k0 == 0 ? adj0 : *(const uint4 *)((const char *)((const uint4 *)p.badj + gw6 * NCB * 64) + ((k0 >> 2) * 1024u + lane * 16u));
                     const unsigned ents4[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
