@@ -355,7 +355,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     //   4. the Brownian noise: no wait in front of it, it runs while the DMAs are in flight.
     // The bead's own position is read from the tile after the barrier (tile index own_base + block-local slot), so no
     // load depends on another one.
-    const size_t gt = rbase + blk * GD_BLOCK + tid;      // tiled path: the thread's record position (balanced thread order)
+    // (tiled path: the thread's records sit at rbase + blk * GD_BLOCK + tid -- the balanced thread order of the build)
     // (its wave index is wave-uniform: chunk addresses are a scalar base + lane, no per-lane 64-bit multiplies)
     const size_t gw6 = (rbase + blk * GD_BLOCK) / 64 + (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)wid);
     const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
@@ -364,7 +364,10 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     uint4 adj0 = make_uint4(0, 0, 0, 0), qa = adj0, qb = adj0;
     unsigned own_base = 0, tile_ok = 0;     // tile_ok == 0: the tile did not fit (flagged by the build; the host rolls the chunk back)
     if (TILED) {
-        mo = p.rec_mo[gt];
+        // (per-thread records, chunks and tile pieces are addressed as a block- / wave-uniform base plus a 32-bit lane offset:
+        // scalar address arithmetic, no 64-bit per-lane adds)
+        const size_t tbase = rbase + (size_t)blk * GD_BLOCK;      // first thread position of the block
+        mo = *(const uint2 *)((const char *)(p.rec_mo + tbase) + tid * 8u);
         const TileDesc *td = p.tiles + (size_t)r * p.nblk + blk;
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES];      // (the LDS base of a range is the sum of the lengths before it: not loaded)
 #pragma unroll
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                 const unsigned len = tlen[k], st = tst[k];
                 for (unsigned q0 = wq; q0 < len; q0 += GD_BLOCK) {      // (wave-uniform loop: scalar control, one compare per lane)
                     if (q0 + lane < len)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(rpos + st + q0) + lane * 16u),
                                                          (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
                 }
             }
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         GD_STAMP(11);     // record + descriptor + DMA issue
         // three more loads per thread, unconditionally (every array is allocated for all threads of the block); nothing
         // before the barrier waits for them
-        rec = p.rec_x0[gt];
+        rec = *(const float4 *)((const char *)(p.rec_x0 + tbase) + tid * 16u);
         adj0 = ((const uint4 *)p.badj)[gw6 * NCB * 64 + lane];
         qa = nt_load((const uint4 *)p.nbr16 + gw6 * NCL * 64 + lane);
         GD_STAMP(8);      // per-bead loads issued
@@ -512,8 +515,10 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             const unsigned nchA = nA;
             unsigned nchB = nB;
             if (MODE == GD_MODE_STEP && TILED) {
-                const float T = cut + __builtin_amdgcn_sqrtf(disp2) + __builtin_amdgcn_sqrtf(dmax0);
-                if (T * 1.00005f < p.rn) nchB = 0u;
+                // T = cutoff + D_i + D < rn  <=>  D_i < S with the block-uniform S = rn - cutoff - D (compared in squares: one square
+                // root per block instead of two per bead)
+                const float S = p.rn * (1.0f / 1.00005f) - cut - __builtin_amdgcn_sqrtf(dmax0);
+                if (S > 0.f && disp2 < S * S) nchB = 0u;
             }
             const unsigned nch = nchA + nchB;
             const unsigned cntp = TILED ? nch * GD_UNROLL : (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
@@ -833,10 +838,12 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             const float mu_dt = mu * p.dt;
             const float sg = s_ctx.sg_uniform >= 0.f ? s_ctx.sg_uniform : sqrtf(2.0f * p.kT * mu_dt);
             const float ex = mu_dt * F.x + sg * z.x, ey = mu_dt * F.y + sg * z.y, ez = mu_dt * F.z + sg * z.z;
-            p.pos_out[g] = make_float4(xi.x + ex, xi.y + ey, xi.z + ez, xi4.w);
+            if (TILED) *(float4 *)((char *)(p.pos_out + rbase + (size_t)blk * GD_BLOCK) + local * 16u) = make_float4(xi.x + ex, xi.y + ey, xi.z + ez, xi4.w);
+            else p.pos_out[g] = make_float4(xi.x + ex, xi.y + ey, xi.z + ez, xi4.w);
             // displacement of the NEW position since the build, bounded by the triangle inequality (the build position
             // need not stay in registers): |x + dx - x0| <= |x - x0| + |dx|
-            if (TILED) { const float dn = __builtin_amdgcn_sqrtf(disp2) + __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez); dnew2 = dn * dn * 1.000001f; }
+            // ((d + e)^2 = d^2 + e^2 + 2 sqrt(d^2 e^2): one square root)
+            if (TILED) { const float e2 = ex * ex + ey * ey + ez * ez; dnew2 = (disp2 + e2 + 2.0f * __builtin_amdgcn_sqrtf(disp2 * e2)) * 1.000002f; }
         } else if (MODE == GD_MODE_FORCE) {
             p.fout[(size_t)r * p.N + oid] = make_float4(F.x, F.y, F.z, 0.f);
         }
