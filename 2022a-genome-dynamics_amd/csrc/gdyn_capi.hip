@@ -160,6 +160,7 @@ struct gd_system {
         size_t idx = 0;
         int settle = 0, measured = 0, wait = 4, rounds = 0;      // wait: accepted chunks before the (next) sweep may start
         uint32_t K_ref = 0;                                      // rebuild interval when the last sweep ended
+        uint32_t cap_ref = 0;                                    // tile class when the last sweep ended
         double acc_ms = 0; uint64_t acc_steps = 0;
     } tuner;
     double pend_dt = 0; int pend_flags = 0;      // timestep and flags of the run that left its last callback pending (GD_RUN_DEFER_CALLBACK)
@@ -966,9 +967,13 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
     if (!full_interval || !(s->a2_ema > 0)) return;
     if (t.done) {      // conditions drift (a relaxation, a growing bead scale): look again, around the width in use, once the
                        // rebuild interval -- the displacement rate -- has moved by a third since the last sweep
+        // ... or the tiles have outgrown the class the width was selected in (fewer resident blocks per CU: another width may
+        // fit the smaller class)
         if (t.wait > 0) t.wait--;
+        if (t.cap_ref == 0 && t.wait <= 45 && s->list_tiled) t.cap_ref = std::max(s->list_tile_cap, 3312u);
         const double k = (double)s->K, k0 = (double)std::max(t.K_ref, 1u);
-        if (t.wait > 0 || (k < 1.33 * k0 && k0 < 1.33 * k)) return;
+        const bool outgrown = s->list_tiled && t.cap_ref > 0 && s->list_tile_cap > t.cap_ref;
+        if (!(outgrown && t.wait <= 40) && (t.wait > 0 || (k < 1.33 * k0 && k0 < 1.33 * k))) return;
         t.done = false; t.cand.clear();
     }
     if (t.cand.empty()) {
@@ -990,6 +995,7 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
         size_t best = 0;
         for (size_t k = 1; k < t.cand.size(); k++) if (t.cost[k] > 0 && t.cost[k] < 0.94 * t.cost[0] && t.cost[k] < t.cost[best]) best = k;
         next = best; t.done = true; t.wait = 50; t.K_ref = interval_for_skin(s, t.cand[best]);
+        t.cap_ref = 0;      // (taken a few chunks on, once the selected width has found its class)
     }
     if (t.cand[next] != s->skin) {
         // the tile class for the new width: tiles scale about with the square of the list radius (rows of cells x their

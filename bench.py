@@ -176,11 +176,11 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
     run_one("S-genome-30k x 128, 2nd-bond spring 0 (variant of SURVEY 8d)",
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, second_bond_spring=0.0, device=dev_index), f3, 4000, budget_steps)
     # (gd_tuning.auto_skin: the list width is selected for the workload from measured chunk times; the relaxation is long enough
-    # for that sweep.  The genome workloads run at the library default, 0.75, which their sweeps confirm.)
+    # for that sweep and for the one that follows when the tiles outgrow their class.  The genome workloads run at the library default, 0.75, which their sweeps confirm.)
     run_one("S-1kb-250k x 4 replicas (periodic, loops + glues static; auto_skin)",
-            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=4, device=dev_index), 0, 5000, budget_steps, tune=dict(auto_skin=1))
+            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=4, device=dev_index), 0, 9000, budget_steps, tune=dict(auto_skin=1))
     run_one("S-1kb-250k x 16 replicas (as many beads per launch as the headline; auto_skin)",
-            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=16, device=dev_index), 0, 5000, budget_steps, tune=dict(auto_skin=1))
+            lambda: wl.chromatin_1kb(hip, n_beads=250000, n_replicas=16, device=dev_index), 0, 9000, budget_steps, tune=dict(auto_skin=1))
     return out
 
 

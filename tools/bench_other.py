@@ -22,8 +22,20 @@ elif which == "abbox":
     s, info = wl.ab_box(hip, n_replicas=R); flags = 0
 dt, kT = info["timestep"], info["temperature"]
 s.set_tuning(skin=skin, kernel_path=path, auto_skin=0 if skin > 0 else int(os.environ.get("AUTO_SKIN", "1" if which == "1kb" else "0")))
+# STATE_OUT=<npy>: relax (with the skin selection), save positions + "<file>.skin" and stop; STATE_IN=<npy>: start from such a
+# state at the saved width (no selection): what the profiler runs, so that its averages cover the settled state only
+if os.environ.get("STATE_IN"):
+    s.set_tuning(skin=float(open(os.environ["STATE_IN"] + ".skin").read()), kernel_path=path)
+    s.set_positions(np.load(os.environ["STATE_IN"]))
+    relax = 0
 s.begin_phase()
-s.run(relax, dt, kT, seed=5, flags=0)
+if relax:
+    s.run(relax, dt, kT, seed=5, flags=0)
+if os.environ.get("STATE_OUT"):
+    np.save(os.environ["STATE_OUT"], s.positions())
+    cut = {"1kb": 1.5}.get(which, 0.3)
+    open(os.environ["STATE_OUT"] + ".skin", "w").write(repr(s.context().list_radius / cut - 1.0))
+    sys.exit(0)
 s.begin_phase()
 s.run(100, dt, kT, seed=6, flags=flags)
 t0 = time.perf_counter(); tm = s.run(steps, dt, kT, seed=7, flags=flags); el = time.perf_counter() - t0
