@@ -979,7 +979,7 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
     if (t.cand.empty()) {
         if (t.wait > 0 && t.rounds == 0) { t.wait--; return; }
         if (t.rounds == 0) t.cand = {s->skin, std::min(1.2 * s->skin, 1.0), 0.7 * s->skin, 0.5 * s->skin, 0.35 * s->skin};
-        else t.cand = {s->skin, std::min(1.4 * s->skin, 1.0), 0.7 * s->skin};
+        else t.cand = {s->skin, std::min(1.2 * s->skin, 1.0), 0.85 * s->skin, 0.7 * s->skin};      // (finer steps around the width in use)
         t.cost.assign(t.cand.size(), 0.0);
         t.idx = 0; t.settle = 0; t.measured = 0; t.acc_ms = 0; t.acc_steps = 0; t.rounds++;
     }

@@ -795,7 +795,7 @@ def test_auto_skin_sweep_keeps_results_and_settles(hip, oracle):
     s.run(6000, info["timestep"], info["temperature"], seed=SEED, flags=flags)
     c = s.context()
     cut = 0.30
-    assert any(abs(c.list_radius - cut * (1 + 0.75 * f)) < 1e-3 for f in (1.0, 1.2, 0.7, 0.5, 0.35, 1.4 * 0.7, 1.4 * 0.5, 0.49, 0.35 * 0.7, 1.2 * 0.7, 4 / 3)), c.list_radius
+    assert cut * 1.1 < c.list_radius < cut * 2.0, c.list_radius          # a width between 0.1 and 1.0 x the cutoff
     assert c.rollbacks <= 8 and c.step == 6000
     so, _ = wl.genome_interphase(oracle, n_beads=6000, n_replicas=1)
     so.set_positions(s.positions()[3][None])
