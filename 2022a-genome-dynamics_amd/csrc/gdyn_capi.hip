@@ -115,6 +115,8 @@ struct gd_system {
     uint32_t sw_n = 0; double sw_eps = 0, sw_decay = 1, sw_cut = 0;     // droplet attraction (gd_set_pair_softwell)
     DevBuf<unsigned> sw_targets; DevBuf<double> sw_esum;
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
+    char *h_chunk = nullptr;       // pinned host block for the per-chunk readback (flags, contexts, list counts): copies into pageable
+                                   // memory are staged by the runtime and cost ~20 us each
     uint32_t tile_hold = 0;        // chunks to stay in the larger tile class after an overflow
     uint32_t last_need_t = 0;      // largest tile of the last build that reported one (entries)
     uint32_t list_tile_cap = 0;    // tile capacity the current list was built with (fixes its entry encoding and LDS need)
@@ -239,6 +241,7 @@ extern "C" int gd_destroy(gd_system *s)
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
+    if (s->h_chunk) (void)hipHostFree(s->h_chunk);
     delete s;
     return GD_OK;
 }
@@ -1142,10 +1145,15 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         std::vector<unsigned> f((size_t)s->R * GD_NFLAGS);
         std::vector<DevCtx> ctx_new(s->R);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(f.data(), s->flags.p, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(ctx_new.data(), s->ctx[s->ccur].p, s->R * sizeof(DevCtx), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(s->lcount.data(), s->lcount_d.p, s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
+        {
+            const size_t nf = f.size() * sizeof(unsigned), nc = s->R * sizeof(DevCtx), nl = s->R * sizeof(unsigned long long);
+            if (!s->h_chunk) HIPCHK(hipHostMalloc((void **)&s->h_chunk, nf + nc + nl, hipHostMallocDefault));
+            HIPCHK(hipMemcpyAsync(s->h_chunk, s->flags.p, nf, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(s->h_chunk + nf, s->ctx[s->ccur].p, nc, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc, s->lcount_d.p, nl, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            memcpy(f.data(), s->h_chunk, nf); memcpy(ctx_new.data(), s->h_chunk + nf, nc); memcpy(s->lcount.data(), s->h_chunk + nf + nc, nl);
+        }
         bool violated = false; float maxd2 = 0;
         for (uint32_t r = 0; r < s->R; r++) {
             violated |= f[r * GD_NFLAGS + GD_FLAG_VIOLATION] != 0;

@@ -22,11 +22,18 @@ def world():
     return 0, 1
 
 
+def _grouped():
+    """True when a process group exists: the collectives then run whatever its size (a one-rank RCCL group on a one-GPU
+    box executes the same broadcast / gather / all-reduce calls as the eight-rank farm); without a group they are identities."""
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized()
+
+
 def broadcast_array(arr, shape, dtype, device="cpu", src=0):
     """Broadcast a numpy array from rank `src`; other ranks pass arr=None."""
     import torch
     rank, n = world()
-    if n == 1:
+    if not _grouped():
         return arr
     t = torch.from_numpy(np.ascontiguousarray(arr)).to(device) if rank == src else \
         torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), device=device)
@@ -39,7 +46,7 @@ def gather_stats(values, device="cpu", dst=0):
     import torch
     rank, n = world()
     v = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if n == 1:
+    if not _grouped():
         return v.cpu().numpy()[None]
     out = [torch.empty_like(v) for _ in range(n)] if rank == dst else None
     _dist().gather(v, out, dst)
@@ -48,8 +55,7 @@ def gather_stats(values, device="cpu", dst=0):
 
 def max_over_ranks(x, device="cpu"):
     import torch
-    rank, n = world()
-    if n == 1:
+    if not _grouped():
         return float(x)
     t = torch.tensor([float(x)], dtype=torch.float64, device=device)
     _dist().all_reduce(t, op=_dist().ReduceOp.MAX)
@@ -57,7 +63,7 @@ def max_over_ranks(x, device="cpu"):
 
 
 def barrier():
-    if world()[1] > 1:
+    if _grouped():
         _dist().barrier()
 
 

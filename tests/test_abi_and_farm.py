@@ -121,6 +121,48 @@ def test_bench_farm_rehearsal_two_ranks_one_gpu(hip):
     assert line["config"]["mean_energy_per_bead"][0] != line["config"]["mean_energy_per_bead"][1]      # independent trajectories
 
 
+@pytest.mark.gpu
+def test_bench_one_rank_under_the_launcher_runs_the_rccl_collectives(hip):
+    """The farm's collectives on the real backend: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` forms a one-rank
+    RCCL group on the MI355X and runs the same calls as the eight-rank farm (communicator set-up, the broadcast of the (R, N, 3)
+    float64 inputs from device memory, barriers, the max-over-ranks all-reduce, the gather of the summary rows)."""
+    import json
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--beads", "3000", "--replicas", "8", "--equil", "200", "--steps", "40", "--warmup", "10",
+                          "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1", NCCL_DEBUG="VERSION"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["dist_backend"] == "nccl"
+    assert line["value"] > 0 and len(line["config"]["mean_energy_per_bead"]) == 1
+
+
+@pytest.mark.gpu
+def test_farm_collectives_on_a_one_rank_rccl_group(hip):
+    """farm.py's four collectives called directly on device tensors of a one-rank RCCL group, values checked."""
+    code = (
+        "import os, sys, importlib, numpy as np, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "farm = importlib.import_module('2022a-genome-dynamics_amd.farm')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "x = np.random.default_rng(3).normal(size=(8, 3000, 3))\n"
+        "y = farm.broadcast_array(x, x.shape, np.float64, device='cuda')\n"
+        "assert y.dtype == np.float64 and np.array_equal(x, y)\n"
+        "g = farm.gather_stats([1.5, -2.0, 3.25], device='cuda')\n"
+        "assert g.shape == (1, 3) and g.tolist() == [[1.5, -2.0, 3.25]]\n"
+        "assert farm.max_over_ranks(0.125, device='cuda') == 0.125\n"
+        "farm.barrier(); torch.cuda.synchronize()\n"
+        "print('RCCL_OK', dist.get_backend(), torch.cuda.nccl.version())\n"
+        "dist.destroy_process_group()\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RCCL_OK nccl" in out.stdout
+
+
 def test_bench_self_launch_builds_the_rank_command_without_touching_torch():
     """`python bench.py --gpus N` without a launcher: the parent only starts N rank processes (torch.distributed.run) and
     must not have imported torch (nothing may initialise the GPU before the ranks exist)."""
