@@ -25,6 +25,7 @@ GD_BOX_OPEN, GD_BOX_PERIODIC = 0, 1
 POT_HARMONIC, POT_SPRING, POT_SEMISPRING, POT_SOFTCORE = 0, 1, 2, 3
 NOISE_PHILOX, NOISE_ZERO, NOISE_HOST, NOISE_MT19937 = 0, 1, 2, 3
 RUN_UPDATE_SCALES, RUN_WALL_DYNAMICS, RUN_DEFER_CALLBACK = 1, 2, 4
+ALL_REPLICAS = 0xffffffff
 TERM_PAIR, TERM_BOND, TERM_BEND, TERM_POINT, TERM_WALL, TERM_DYNAMIC, TERM_ALL = 1, 2, 4, 8, 16, 32, 63
 
 _STATUS = {1: "GD_EINVAL", 2: "GD_ENODEVICE", 3: "GD_EHIP", 4: "GD_ENOMEM", 5: "GD_ESTATE", 6: "GD_EUNSUPPORTED"}
@@ -100,7 +101,7 @@ ABI_SYMBOLS = [
     "gd_add_bond_pairs", "gd_set_dynamic_pairs", "gd_add_bending_range", "gd_add_point_source",
     "gd_set_ellipsoid_wall", "gd_set_inner_sphere_wall", "gd_set_pair_softwell", "gd_set_scaling", "gd_get_context", "gd_begin_phase", "gd_set_context",
     "gd_run", "gd_apply_callback", "gd_compute_energy", "gd_compute_forces", "gd_search_pairs", "gd_set_tuning",
-    "gd_get_timing", "gd_get_stream",
+    "gd_get_timing", "gd_get_stream", "gd_contacts_update", "gd_contacts_fetch", "gd_contacts_clear",
 ]
 
 
@@ -152,6 +153,9 @@ class Lib:
         d.gd_compute_forces.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
         d.gd_search_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.c_uint64,
                                       C.POINTER(C.c_uint64)]
+        d.gd_contacts_update.argtypes = [C.c_void_p, C.c_double]
+        d.gd_contacts_fetch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]
+        d.gd_contacts_clear.argtypes = [C.c_void_p, C.c_uint32]
         d.gd_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
         d.gd_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         d.gd_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -353,6 +357,22 @@ class System:
         if n.value:
             self.lib.check(self.lib.dll.gd_search_pairs(self._h, replica, dcut, _uptr(out), n.value, C.byref(n)))
         return out
+
+    def contacts_update(self, distance):
+        """contact_map::update of every replica (contact_map.cc:31-74)."""
+        self.lib.check(self.lib.dll.gd_contacts_update(self._h, distance))
+
+    def contacts(self, replica=0):
+        """contact_map::accumulate (contact_map.cc:77-91): (n, 3) uint32 rows (i, j, count), row-major order."""
+        n = C.c_uint64(0)
+        self.lib.check(self.lib.dll.gd_contacts_fetch(self._h, replica, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3), dtype=np.uint32)
+        if n.value:
+            self.lib.check(self.lib.dll.gd_contacts_fetch(self._h, replica, _uptr(out), n.value, C.byref(n)))
+        return out
+
+    def contacts_clear(self, replica=ALL_REPLICAS):
+        self.lib.check(self.lib.dll.gd_contacts_clear(self._h, replica))
 
     def set_tuning(self, skin=0.0, rebuild_interval=0, adapt_interval=1, list_width=0, kernel_path=0, near_fraction=0.0, auto_skin=0):
         t = Tuning(skin, rebuild_interval, adapt_interval, list_width, kernel_path, near_fraction, auto_skin)

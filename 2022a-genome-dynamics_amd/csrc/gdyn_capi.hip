@@ -170,6 +170,10 @@ struct gd_system {
     // gd_search_pairs: device output, counters, and the cached result of the last call
     DevBuf<uint2> sp_out; DevBuf<unsigned long long> sp_count; std::vector<uint2> sp_host;
     bool sp_valid = false; uint32_t sp_r = 0; double sp_dcut = 0; uint64_t sp_serial = 0;
+    // gd_contacts_*: per-replica count tables (ContactTab), the pair buffer of an update, dump buffers
+    DevBuf<unsigned long long> ct_words; DevBuf<unsigned> ct_distinct; size_t ct_cap = 0;
+    DevBuf<uint2> ct_pairs; DevBuf<unsigned long long> ct_count; std::vector<unsigned> ct_distinct_h;
+    DevBuf<unsigned long long> ct_ck[2]; DevBuf<unsigned> ct_cv[2], ct_n; DevBuf<char> ct_tmp;
     uint64_t state_serial = 1;     // bumped by everything that changes positions or the model (invalidates the cache)
     int ocur = 0;   // which orig[] buffer is current
     std::vector<hipEvent_t> events;
@@ -1275,6 +1279,52 @@ extern "C" int gd_compute_forces(gd_system *s, uint32_t mask, double *forces)
     return GD_OK;
 }
 
+// Pairs within dcut of replicas r0 .. r0 + nrep - 1, one launch: replica r0 + y's pairs at out + y * (out.n / nrep), their number in
+// cnt[2 y] (and left on the device in `count`).  The buffer grows until every replica fits.
+static int search_device(gd_system *s, uint32_t r0, uint32_t nrep, double dcut, DevBuf<uint2> &out, DevBuf<unsigned long long> &count,
+                         std::vector<unsigned long long> &cnt)
+{
+    const bool with_list = pair_cutoff(s) > 0;
+    if (!out.p || out.n % nrep) HIPCHK(out.resize((size_t)nrep * std::max<size_t>((size_t)s->N * 8, 4096), false));
+    HIPCHK(count.resize(2 * (size_t)nrep));
+    cnt.assign(2 * (size_t)nrep, 0ull);
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (!s->list_valid || !((float)dcut <= s->rv) || s->list_W == 0) {
+            // the list stays in use as the force list of the next run: built with that run's look-ahead (a growing bead
+            // scale over the rest of an interval), like the builds inside gd_run
+            gd_run_desc ahead{};
+            ahead.timestep = s->last_dt; ahead.flags = s->last_flags;
+            const float rv_force = with_list ? list_radius(s, s->last_dt > 0 ? &ahead : nullptr, s->K) : 0.f;
+            const float rv_search = (float)(dcut * (1.0 + 1e-6));
+            GDCHK(build_now(s, std::max(rv_force, rv_search), true));
+            s->list_valid = true; s->search_list = rv_search > rv_force;
+        }
+        const double lim = 0.5 * ((double)s->rv - dcut);
+        PairsP q;
+        memset(&q, 0, sizeof q);
+        q.pos = s->pos[s->pcur].p; q.x0 = s->list_tiled ? s->rec_x0.p : s->xb.p; q.rec_mo = s->rec_mo.p; q.meta = s->meta.p;
+        q.orig = s->orig[s->ocur].p; q.nbr = s->nbr.p; q.nbr16 = s->nbr16.p; q.tiles = s->tiles.p;
+        q.N = s->N; q.Np = s->Np; q.nblk = s->nblk; q.r = r0; q.nrep = nrep; q.W = s->list_W;
+        q.tiled = s->list_tiled ? 1 : 0; q.s16 = (s->list_tiled && s->list_tile_cap < 4096u) ? 1 : 0;
+        q.periodic = s->box_kind == GD_BOX_PERIODIC;
+        for (int k = 0; k < 3; k++) { q.box[k] = (float)s->box[k]; q.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
+        q.dcut2 = (float)(dcut * dcut); q.lim2 = (float)(lim * lim);
+        q.out = out.p; q.cap = out.n / nrep; q.count = count.p;
+        q.dmax = s->dmax.p;
+        HIPCHK(hipMemsetAsync(count.p, 0, 2 * (size_t)nrep * sizeof(unsigned long long), s->stream));
+        gd_launch_pairs(q, s->stream);
+        HIPCHK(hipMemcpyAsync(cnt.data(), count.p, 2 * (size_t)nrep * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipGetLastError());
+        unsigned long long moved = 0, most = 0;
+        for (uint32_t y = 0; y < nrep; y++) { most = std::max(most, cnt[2 * y]); moved |= cnt[2 * y + 1]; }
+        if (moved) { s->list_valid = false; continue; }                  // a bead moved beyond the margin: fresh list
+        if (most > q.cap) { HIPCHK(out.resize((size_t)nrep * (size_t)(most + most / 8 + 64), false)); continue; }
+        return GD_OK;
+    }
+    return fail(GD_ESTATE, "pair search: did not converge");
+}
+
 // md::neighbor_searcher{box, dcut}.search(): served on the device from the resident Verlet list when that list is
 // complete for dcut (dcut + 2 x largest displacement since the build <= list radius), after ONE list build otherwise -- a
 // build at radius max(force-list radius, dcut), so the force list stays valid either way and the next gd_run does not rebuild.
@@ -1285,50 +1335,115 @@ extern "C" int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *
     if (r >= s->R || !(dcut > 0)) return fail(GD_EINVAL, "gd_search_pairs: bad replica or cutoff");
     GDCHK(prepare(s));
     if (!(s->sp_valid && s->sp_r == r && s->sp_dcut == dcut && s->sp_serial == s->state_serial)) {
-        const bool with_list = pair_cutoff(s) > 0;
-        if (!s->sp_out.p) HIPCHK(s->sp_out.resize(std::max<size_t>((size_t)s->N * 8, 4096), false));
-        HIPCHK(s->sp_count.resize(2));
-        bool done = false;
-        for (int attempt = 0; attempt < 6 && !done; attempt++) {
-            if (!s->list_valid || !((float)dcut <= s->rv) || s->list_W == 0) {
-                // the list stays in use as the force list of the next run: built with that run's look-ahead (a growing bead
-                // scale over the rest of an interval), like the builds inside gd_run
-                gd_run_desc ahead{};
-                ahead.timestep = s->last_dt; ahead.flags = s->last_flags;
-                const float rv_force = with_list ? list_radius(s, s->last_dt > 0 ? &ahead : nullptr, s->K) : 0.f;
-                const float rv_search = (float)(dcut * (1.0 + 1e-6));
-                GDCHK(build_now(s, std::max(rv_force, rv_search), true));
-                s->list_valid = true; s->search_list = rv_search > rv_force;
-            }
-            const double lim = 0.5 * ((double)s->rv - dcut);
-            PairsP q;
-            memset(&q, 0, sizeof q);
-            q.pos = s->pos[s->pcur].p; q.x0 = s->list_tiled ? s->rec_x0.p : s->xb.p; q.rec_mo = s->rec_mo.p; q.meta = s->meta.p;
-            q.orig = s->orig[s->ocur].p; q.nbr = s->nbr.p; q.nbr16 = s->nbr16.p; q.tiles = s->tiles.p;
-            q.N = s->N; q.Np = s->Np; q.nblk = s->nblk; q.r = r; q.W = s->list_W;
-            q.tiled = s->list_tiled ? 1 : 0; q.s16 = (s->list_tiled && s->list_tile_cap < 4096u) ? 1 : 0;
-            q.periodic = s->box_kind == GD_BOX_PERIODIC;
-            for (int k = 0; k < 3; k++) { q.box[k] = (float)s->box[k]; q.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
-            q.dcut2 = (float)(dcut * dcut); q.lim2 = (float)(lim * lim);
-            q.out = s->sp_out.p; q.cap = s->sp_out.n; q.count = s->sp_count.p;
-            HIPCHK(hipMemsetAsync(s->sp_count.p, 0, 2 * sizeof(unsigned long long), s->stream));
-            gd_launch_pairs(q, s->stream);
-            unsigned long long cnt[2] = {0, 0};
-            HIPCHK(hipMemcpyAsync(cnt, s->sp_count.p, sizeof cnt, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipStreamSynchronize(s->stream));
-            HIPCHK(hipGetLastError());
-            if (cnt[1]) { s->list_valid = false; continue; }                 // a bead moved beyond the margin: fresh list
-            if (cnt[0] > s->sp_out.n) { HIPCHK(s->sp_out.resize((size_t)(cnt[0] + cnt[0] / 8 + 64), false)); continue; }
-            s->sp_host.resize((size_t)cnt[0]);
-            if (cnt[0]) HIPCHK(hipMemcpy(s->sp_host.data(), s->sp_out.p, (size_t)cnt[0] * sizeof(uint2), hipMemcpyDeviceToHost));
-            done = true;
-        }
-        if (!done) return fail(GD_ESTATE, "gd_search_pairs: did not converge");
+        std::vector<unsigned long long> cnt;
+        GDCHK(search_device(s, r, 1, dcut, s->sp_out, s->sp_count, cnt));
+        s->sp_host.resize((size_t)cnt[0]);
+        if (cnt[0]) HIPCHK(hipMemcpy(s->sp_host.data(), s->sp_out.p, (size_t)cnt[0] * sizeof(uint2), hipMemcpyDeviceToHost));
         s->sp_valid = true; s->sp_r = r; s->sp_dcut = dcut; s->sp_serial = s->state_serial;
     }
     const uint64_t n = s->sp_host.size();
     for (uint64_t k = 0; k < n && k < cap; k++) { pairs[2 * k] = s->sp_host[k].x; pairs[2 * k + 1] = s->sp_host[k].y; }
     *n_pairs = n;
+    return GD_OK;
+}
+
+// ------------------------------------------------------------- contact maps
+// contact_map (simulation_interphase/contact_map.cc:26-91) on the device, for all replicas of the handle at once: update() = one
+// pair search over every replica + one insert launch into the per-replica count tables; nothing but R pair counts crosses PCIe
+// until a map is dumped.  The tables share one capacity (a power of two) and are grown AHEAD of an update so that no table is more
+// than half full after it, whatever the update adds (the search has already counted the pairs when the tables are sized).
+static unsigned contact_jbits(const gd_system *s)      // bits of a bead id
+{
+    unsigned b = 1;
+    while (((uint64_t)(s->N - 1) >> b) != 0) b++;
+    return b;
+}
+
+static ContactTab contact_tab(gd_system *s)
+{
+    ContactTab t;
+    t.words = s->ct_words.p; t.distinct = s->ct_distinct.p; t.cap = s->ct_cap; t.jbits = contact_jbits(s);
+    return t;
+}
+
+extern "C" int gd_contacts_update(gd_system *s, double distance)
+{
+    if (!s) return fail(GD_EINVAL, "gd_contacts_update: NULL argument");
+    if (!(distance > 0)) return fail(GD_EINVAL, "gd_contacts_update: the contact distance must be positive");
+    if (contact_jbits(s) > 20) return fail(GD_EINVAL, "gd_contacts_update: contact maps take at most 1 048 576 beads (the count shares a 64-bit word with the pair)");
+    GDCHK(prepare(s));
+    std::vector<unsigned long long> cnt;
+    GDCHK(search_device(s, 0, s->R, distance, s->ct_pairs, s->ct_count, cnt));
+    if (s->ct_distinct_h.size() != s->R) s->ct_distinct_h.assign(s->R, 0u);
+    unsigned long long need = 0, most = 0;
+    for (uint32_t r = 0; r < s->R; r++) { need = std::max(need, s->ct_distinct_h[r] + cnt[2 * r]); most = std::max(most, cnt[2 * r]); }
+    size_t cap = std::max<size_t>(s->ct_cap, 1024);
+    while (cap < 2 * need) cap *= 2;
+    if (cap != s->ct_cap) {
+        DevBuf<unsigned long long> words;
+        HIPCHK(words.resize((size_t)s->R * cap, false));
+        HIPCHK(hipMemsetAsync(words.p, 0xff, words.n * sizeof(unsigned long long), s->stream));
+        if (s->ct_cap) {
+            ContactTab to = contact_tab(s), from = to;
+            to.words = words.p; to.cap = cap;
+            HIPCHK(hipMemsetAsync(s->ct_distinct.p, 0, s->R * sizeof(unsigned), s->stream));      // (recounted by the rehash)
+            gd_launch_contacts_rehash(from, to, s->R, s->stream);
+            HIPCHK(hipStreamSynchronize(s->stream));      // the old tables are freed below
+        } else HIPCHK(s->ct_distinct.resize(s->R));
+        std::swap(s->ct_words.p, words.p); std::swap(s->ct_words.n, words.n);
+        s->ct_cap = cap;
+    }
+    gd_launch_contacts_insert(contact_tab(s), s->ct_pairs.p, s->ct_pairs.n / s->R, s->ct_count.p, most, s->R, s->stream);
+    HIPCHK(hipMemcpyAsync(s->ct_distinct_h.data(), s->ct_distinct.p, s->R * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    return GD_OK;
+}
+
+extern "C" int gd_contacts_fetch(gd_system *s, uint32_t r, uint32_t *rows, uint64_t cap, uint64_t *n_rows)
+{
+    if (!s || !n_rows || (cap && !rows)) return fail(GD_EINVAL, "gd_contacts_fetch: NULL argument");
+    if (r >= s->R) return fail(GD_EINVAL, "gd_contacts_fetch: bad replica");
+    const uint64_t n = s->ct_cap ? s->ct_distinct_h[r] : 0;
+    *n_rows = n;
+    if (!n || !cap) return GD_OK;       // (the count of the count-then-fetch idiom costs nothing: the host mirrors the occupancy)
+    HIPCHK(hipSetDevice(s->device));
+    for (int k = 0; k < 2; k++)
+        if (s->ct_ck[k].n < n) { HIPCHK(s->ct_ck[k].resize((size_t)(n + n / 4), false)); HIPCHK(s->ct_cv[k].resize((size_t)(n + n / 4), false)); }
+    HIPCHK(s->ct_n.resize(1));
+    HIPCHK(hipMemsetAsync(s->ct_n.p, 0, sizeof(unsigned), s->stream));
+    gd_launch_contacts_compact(contact_tab(s), r, s->ct_ck[0].p, s->ct_cv[0].p, s->ct_n.p, s->stream);
+    const unsigned jb = contact_jbits(s), bits = 2 * jb;      // key = i << jb | j
+    size_t tmp_bytes = 0;
+    HIPCHK(gd_sort_contacts(nullptr, &tmp_bytes, s->ct_ck[0].p, s->ct_ck[1].p, s->ct_cv[0].p, s->ct_cv[1].p, (size_t)n, bits, s->stream));
+    if (s->ct_tmp.n < tmp_bytes) HIPCHK(s->ct_tmp.resize(tmp_bytes + tmp_bytes / 4, false));
+    tmp_bytes = s->ct_tmp.n;
+    HIPCHK(gd_sort_contacts(s->ct_tmp.p, &tmp_bytes, s->ct_ck[0].p, s->ct_ck[1].p, s->ct_cv[0].p, s->ct_cv[1].p, (size_t)n, bits, s->stream));
+    std::vector<unsigned long long> hk((size_t)n); std::vector<unsigned> hv((size_t)n);
+    unsigned found = 0;
+    HIPCHK(hipMemcpyAsync(hk.data(), s->ct_ck[1].p, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(hv.data(), s->ct_cv[1].p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(&found, s->ct_n.p, sizeof found, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    if (found != n) return fail(GD_ESTATE, "gd_contacts_fetch: table occupancy %u differs from the %llu entries counted", found, (unsigned long long)n);
+    for (uint64_t k = 0; k < n && k < cap; k++) {
+        rows[3 * k] = (uint32_t)(hk[k] >> jb); rows[3 * k + 1] = (uint32_t)(hk[k] & ((1ull << jb) - 1ull)); rows[3 * k + 2] = hv[k];
+    }
+    return GD_OK;
+}
+
+extern "C" int gd_contacts_clear(gd_system *s, uint32_t r)
+{
+    if (!s) return fail(GD_EINVAL, "gd_contacts_clear: NULL argument");
+    if (r != GD_ALL_REPLICAS && r >= s->R) return fail(GD_EINVAL, "gd_contacts_clear: bad replica");
+    if (!s->ct_cap) return GD_OK;
+    HIPCHK(hipSetDevice(s->device));
+    const uint32_t r0 = r == GD_ALL_REPLICAS ? 0 : r, nr = r == GD_ALL_REPLICAS ? s->R : 1;
+    HIPCHK(hipMemsetAsync(s->ct_words.p + (size_t)r0 * s->ct_cap, 0xff, (size_t)nr * s->ct_cap * sizeof(unsigned long long), s->stream));
+    HIPCHK(hipMemsetAsync(s->ct_distinct.p + r0, 0, nr * sizeof(unsigned), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (uint32_t k = r0; k < r0 + nr; k++) s->ct_distinct_h[k] = 0;
     return GD_OK;
 }
 

@@ -17,10 +17,13 @@
 //                          slot order, tile descriptors, list fill (27-cell sweep from the LDS tile, or from global
 //                          memory on the generic path).
 //   k_pairs                pair search (contact map, glue candidates) filtered from the resident list.
+//   k_ct_*                 time-integrated contact maps in HBM (per-replica hash tables: insert, grow, dump).
 //   GD_STAMP / GD_FSTAMP   in-kernel section stamps of the developer timing builds (gdyn_stamps.h; empty in the product).
 //
 // MFMA is not used: the path is an irregular short-range N-body sum.
 #include <hip/hip_fp16.h>
+
+#include <algorithm>
 
 #include "gdyn_types.h"
 
@@ -1760,10 +1763,16 @@ template <bool TILED>
 __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
 {
     __shared__ TileDesc s_td;
-    const unsigned blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const size_t rbase = (size_t)p.r * p.Np, gt = rbase + blk * GD_BLOCK + tid;
+    const unsigned blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, ry = blockIdx.y, rr = p.r + ry;
+    const size_t rbase = (size_t)rr * p.Np, gt = rbase + blk * GD_BLOCK + tid;
+    unsigned long long *__restrict__ count = p.count + 2u * ry;
+    uint2 *__restrict__ out = p.out + (size_t)ry * p.cap;
+    if (p.dmax && __uint_as_float(p.dmax[(size_t)rr * GD_DMAX_STRIDE]) > p.lim2) {      // (block-uniform: the whole replica leaves at once)
+        if (tid == 0) count[1] = 1ull;
+        return;
+    }
     if (TILED) {
-        const unsigned *src = (const unsigned *)(p.tiles + (size_t)p.r * p.nblk + blk);
+        const unsigned *src = (const unsigned *)(p.tiles + (size_t)rr * p.nblk + blk);
         if (tid < sizeof(TileDesc) / 4) ((unsigned *)&s_td)[tid] = src[tid];
         __syncthreads();
     }
@@ -1782,7 +1791,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
         xi = rpos[slot]; oi = p.orig[rbase + slot];
         const float4 x0 = TILED ? p.x0[gt] : p.x0[rbase + slot];
         const float dx = xi.x - x0.x, dy = xi.y - x0.y, dz = xi.z - x0.z;
-        if (dx * dx + dy * dy + dz * dz > p.lim2) p.count[1] = 1ull;
+        if (dx * dx + dy * dy + dz * dz > p.lim2) count[1] = 1ull;
     } else cnt = 0;
     const size_t gl = TILED ? gt : rbase + slot;
     const unsigned PER = TILED ? 8u : 4u, NC = p.W / PER;
@@ -1807,25 +1816,122 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
         oj = p.orig[rbase + js];
         return oi < oj;
     };
+    // first pass: count, and remember the hits among the first 64 entries (most lists) so that the second pass only decodes those
     unsigned n = 0, oj;
-    for (unsigned k = 0; k < cnt; k++) n += close_pair(partner(k), oj) ? 1u : 0u;
+    unsigned long long hits = 0;
+    for (unsigned k = 0; k < cnt; k++) {
+        const bool c = close_pair(partner(k), oj);
+        n += c ? 1u : 0u;
+        if (c && k < 64u) hits |= 1ull << k;
+    }
     // wave-aggregated append: exclusive scan of the lane counts, one atomic per wave
     unsigned incl = n;
     for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
     const unsigned total = __shfl(incl, 63, 64);
     unsigned long long base = 0;
-    if (lane == 63 && total) base = atomicAdd(p.count, (unsigned long long)total);
+    if (lane == 63 && total) base = atomicAdd(count, (unsigned long long)total);
     base = __shfl(base, 63, 64);
     unsigned long long at = base + (incl - n);
-    if (n && at + n <= p.cap)
-        for (unsigned k = 0; k < cnt; k++)
-            if (close_pair(partner(k), oj)) p.out[at++] = make_uint2(oi, oj);
+    if (n && at + n <= p.cap) {
+        while (hits) {
+            const unsigned k = (unsigned)__ffsll((long long)hits) - 1u;
+            hits &= hits - 1ull;
+            out[at++] = make_uint2(oi, p.orig[rbase + partner(k)]);
+        }
+        for (unsigned k = 64u; k < cnt; k++)
+            if (close_pair(partner(k), oj)) out[at++] = make_uint2(oi, oj);
+    }
 }
 
 void gd_launch_pairs(const PairsP &p, hipStream_t st)
 {
-    if (p.tiled) hipLaunchKernelGGL(k_pairs<true>, dim3(p.nblk), dim3(GD_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL(k_pairs<false>, dim3(p.nblk), dim3(GD_BLOCK), 0, st, p);
+    const dim3 grid(p.nblk, p.nrep ? p.nrep : 1u);
+    if (p.tiled) hipLaunchKernelGGL(k_pairs<true>, grid, dim3(GD_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL(k_pairs<false>, grid, dim3(GD_BLOCK), 0, st, p);
+}
+
+// ------------------------------------------------------------- contact maps
+// contact_map::update (simulation_interphase/contact_map.cc:31-74) adds a 0/1 matrix of the pairs in contact to a sparse count
+// matrix; here the count matrix of a replica is an open-addressing table in HBM (linear probing, at most half full: the host
+// grows it ahead of an update), so that neither the pairs nor the counts leave the device between two dumps.
+__device__ __forceinline__ unsigned long long ct_hash(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+__device__ __forceinline__ void ct_add(unsigned long long *words, unsigned *distinct, unsigned long long mask, unsigned cbits,
+                                       unsigned long long key, unsigned long long add)
+{
+    unsigned long long h = ct_hash(key) & mask;
+    for (unsigned long long probe = 0; probe <= mask; probe++, h = (h + 1ull) & mask) {      // (terminates: the table is never full)
+        unsigned long long w = words[h];
+        if (w == GD_CT_EMPTY) {
+            w = atomicCAS(&words[h], GD_CT_EMPTY, (key << cbits) | add);
+            if (w == GD_CT_EMPTY) { atomicAdd(distinct, 1u); return; }
+        }
+        if ((w >> cbits) == key) { atomicAdd(&words[h], add); return; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ct_insert(const ContactTab t, const uint2 *__restrict__ pairs, unsigned long long cap_pairs,
+                                                   const unsigned long long *__restrict__ count)
+{
+    const unsigned r = blockIdx.y;
+    const unsigned long long n = min(count[2u * r], cap_pairs);
+    unsigned long long *words = t.words + (size_t)r * t.cap;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint2 q = pairs[(size_t)r * cap_pairs + k];
+        ct_add(words, t.distinct + r, t.cap - 1ull, 64u - 2u * t.jbits, ((unsigned long long)q.x << t.jbits) | q.y, 1ull);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ct_rehash(const ContactTab from, const ContactTab to)
+{
+    const unsigned r = blockIdx.y, cbits = 64u - 2u * from.jbits;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < from.cap; k += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long w = from.words[(size_t)r * from.cap + k];
+        if (w != GD_CT_EMPTY) ct_add(to.words + (size_t)r * to.cap, to.distinct + r, to.cap - 1ull, cbits, w >> cbits, w & ((1ull << cbits) - 1ull));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ct_compact(const ContactTab t, unsigned r, unsigned long long *__restrict__ keys_out,
+                                                    unsigned *__restrict__ vals_out, unsigned *n_out)
+{
+    const unsigned lane = threadIdx.x & 63, cbits = 64u - 2u * t.jbits;
+    const unsigned long long nround = (t.cap + 255ull) & ~255ull;      // whole waves take part in the ballot
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < nround; k += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long w = k < t.cap ? t.words[(size_t)r * t.cap + k] : GD_CT_EMPTY;
+        const bool used = w != GD_CT_EMPTY;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(used);
+        unsigned base = 0;
+        if (lane == 0 && m) base = atomicAdd(n_out, (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, 0, 64);
+        if (used) {
+            const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            keys_out[at] = w >> cbits; vals_out[at] = (unsigned)(w & ((1ull << cbits) - 1ull));
+        }
+    }
+}
+
+void gd_launch_contacts_insert(const ContactTab &t, const uint2 *pairs, unsigned long long cap_pairs, const unsigned long long *count,
+                               unsigned long long max_count, unsigned R, hipStream_t st)
+{
+    if (!max_count) return;
+    const unsigned nb = (unsigned)std::min<unsigned long long>((max_count + 255ull) / 256ull, 4096ull);
+    hipLaunchKernelGGL(k_ct_insert, dim3(nb, R), dim3(256), 0, st, t, pairs, cap_pairs, count);
+}
+
+void gd_launch_contacts_rehash(const ContactTab &from, const ContactTab &to, unsigned R, hipStream_t st)
+{
+    const unsigned nb = (unsigned)std::min<unsigned long long>((from.cap + 255ull) / 256ull, 4096ull);
+    hipLaunchKernelGGL(k_ct_rehash, dim3(nb, R), dim3(256), 0, st, from, to);
+}
+
+void gd_launch_contacts_compact(const ContactTab &t, unsigned r, unsigned long long *keys_out, unsigned *vals_out, unsigned *n_out, hipStream_t st)
+{
+    const unsigned nb = (unsigned)std::min<unsigned long long>((t.cap + 255ull) / 256ull, 8192ull);
+    hipLaunchKernelGGL(k_ct_compact, dim3(nb), dim3(256), 0, st, t, r, keys_out, vals_out, n_out);
 }
 
 // ------------------------------------------------------------------- misc

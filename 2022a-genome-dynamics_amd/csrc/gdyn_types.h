@@ -270,10 +270,34 @@ struct PairsP {
     int tiled, s16, periodic;
     float box[3], inv_box[3];
     float dcut2, lim2;                  // lim2: largest squared displacement since the build for which the list still holds every pair within dcut
-    uint2 *out; unsigned long long cap;
-    unsigned long long *count;          // [0] pairs found, [1] != 0: some bead has moved too far (the caller rebuilds)
+    uint2 *out; unsigned long long cap; // replica r + y of a multi-replica launch writes at out + y * cap
+    unsigned long long *count;          // per replica of the launch: [2y] pairs found, [2y + 1] != 0: some bead has moved too far (the caller rebuilds)
+    unsigned nrep;                      // replicas r .. r + nrep - 1 in one launch (grid.y)
+    const unsigned *dmax;               // [R] x GD_DMAX_STRIDE: k_step's running bound of the squared displacement since the build (float
+                                        // bits), or NULL: a replica whose bound already exceeds lim2 is flagged by its first wave and skipped
 };
 void gd_launch_pairs(const PairsP &p, hipStream_t st);
+
+// Time-integrated contact maps (gd_contacts_*; simulation_interphase/contact_map.cc:31-91): one open-addressing table per replica,
+// one 64-bit word per slot = (i << jbits | j) << cbits | count (bead ids i < j < 2^jbits, cbits = 64 - 2 jbits >= 24 count bits;
+// all ones = empty slot: no pair has i all ones), so that counting a pair that is already in the table is ONE random access: a
+// load that finds the key and a 64-bit atomic add on the same word.
+#define GD_CT_EMPTY 0xffffffffffffffffull
+struct ContactTab {
+    unsigned long long *words;          // [R][cap]
+    unsigned *distinct;                 // [R] occupied slots
+    unsigned long long cap;             // slots per replica, a power of two
+    unsigned jbits;                     // bits of a bead id
+};
+// count the pairs of `pairs` (cap_pairs per replica, count[2y] valid) into the tables of all R replicas
+void gd_launch_contacts_insert(const ContactTab &t, const uint2 *pairs, unsigned long long cap_pairs, const unsigned long long *count,
+                               unsigned long long max_count, unsigned R, hipStream_t st);
+void gd_launch_contacts_rehash(const ContactTab &from, const ContactTab &to, unsigned R, hipStream_t st);      // (to: cleared, distinct zeroed)
+// occupied slots of replica r -> keys_out (i << jbits | j) / vals_out (any order), *n_out = their number
+void gd_launch_contacts_compact(const ContactTab &t, unsigned r, unsigned long long *keys_out, unsigned *vals_out, unsigned *n_out, hipStream_t st);
+// gdyn_sort.hip: ascending radix sort of (key, value) pairs (rocPRIM); tmp == nullptr: only *tmp_bytes is set
+hipError_t gd_sort_contacts(void *tmp, size_t *tmp_bytes, const unsigned long long *kin, unsigned long long *kout, const unsigned *vin,
+                            unsigned *vout, size_t n, unsigned key_bits, hipStream_t st);
 void gd_launch_gather_xyz(const float4 *pos, const unsigned *slot_of, float *out, unsigned N, unsigned Np, unsigned R, int quantize,
                           hipStream_t st);
 void gd_launch_gather_positions(const float4 *pos, const unsigned *slot_of, float4 *out, unsigned N, unsigned Np,

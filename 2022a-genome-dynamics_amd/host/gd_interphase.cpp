@@ -18,7 +18,6 @@
 #include <ctime>
 #include <iomanip>
 #include <iostream>
-#include <map>
 #include <memory>
 #include <random>
 #include <stdexcept>
@@ -34,33 +33,16 @@ namespace {
 
 using gd::chk;
 
-// Time-integrated contact map (simulation_interphase/contact_map.cc:31-91): unique pairs (i<j) within the
-// contact distance are counted at every update; accumulate() lists (i, j, count) in row-major order.
-class contact_map {
-public:
-    void set_contact_distance(double d) { _distance = d; }
-    void clear() { _counts.clear(); }
-    void update(gd_system *sys, uint32_t replica)
-    {
-        if (!(_distance > 0)) return;     // the reference's default distance is 0 until the first callback set it
-        uint64_t n = 0;
-        chk(gd_search_pairs(sys, replica, _distance, nullptr, 0, &n));       // (the library keeps the result for the fetch)
-        _buffer.resize(2 * n);
-        if (n) chk(gd_search_pairs(sys, replica, _distance, _buffer.data(), n, &n));
-        for (uint64_t k = 0; k < n; k++) _counts[{_buffer[2 * k], _buffer[2 * k + 1]}] += 1;
-    }
-    std::vector<std::array<std::uint32_t, 3>> accumulate() const
-    {
-        std::vector<std::array<std::uint32_t, 3>> out;
-        out.reserve(_counts.size());
-        for (auto const &kv : _counts) out.push_back({kv.first.first, kv.first.second, kv.second});
-        return out;
-    }
-private:
-    double _distance = 0;
-    std::map<std::pair<std::uint32_t, std::uint32_t>, std::uint32_t> _counts;
-    std::vector<std::uint32_t> _buffer;
-};
+// Time-integrated contact maps (simulation_interphase/contact_map.cc:26-91) live on the device, one per replica (gd_contacts_*):
+// an update is one pair search over all replicas plus one insert launch, and only a dump moves rows to the host.
+std::vector<std::array<std::uint32_t, 3>> fetch_contacts(gd_system *sys, uint32_t replica)
+{
+    uint64_t n = 0;
+    chk(gd_contacts_fetch(sys, replica, nullptr, 0, &n));
+    std::vector<std::array<std::uint32_t, 3>> rows(n);
+    if (n) chk(gd_contacts_fetch(sys, replica, rows.data()->data(), n, &n));
+    return rows;
+}
 
 // One driver = one libgdyn handle = R replicas = R trajectory files.  R = 1 is the reference program; R > 1 batches R runs
 // of the reference's ensemble (one process per seed, each with its own prepared file: 5-sim-genome/scripts/run_simulation:8-25,
@@ -118,7 +100,6 @@ private:
         c.wall_semiaxes[2] = _config.wall_init_semiaxes.z;
         c.bead_scale = _config.bead_scale_init; c.bond_scale = _config.bond_scale_init;
         _context.assign(_R, c);
-        _contacts.resize(_R);
         _buffer.resize(3 * _n * _R);
         _energy.resize(_R);
     }
@@ -171,8 +152,9 @@ private:
             chk(gd_get_context(_sys, (uint32_t)r, &ctx));
             _context[r].bead_scale = ctx.bead_scale; _context[r].bond_scale = ctx.bond_scale;
             std::copy(ctx.semiaxes, ctx.semiaxes + 3, _context[r].wall_semiaxes);
-            _contacts[r].set_contact_distance(_config.contactmap_distance * ctx.bead_scale);     // set by update_bead_scale() of callback(target - 1), :66
         }
+        _contact_distance = _config.contactmap_distance * _context[0].bead_scale;     // set by update_bead_scale() of callback(target - 1), :66
+                                                                                      // (replicas of one handle are at the same step: one scale)
         step = target;
     }
 
@@ -231,10 +213,12 @@ private:
             if (logging || sampling) mean_energy();
             if (logging) print_progress("inter", step);
             if (sampling) save_snapshot(step);
-            if (step % _config.contactmap_update_interval == 0)
-                for (std::size_t r = 0; r < _R; r++) _contacts[r].update(_sys, (uint32_t)r);
-            if (sampling && frame % _config.contactmap_thinning_rate == 0)
-                for (std::size_t r = 0; r < _R; r++) { _stores[r]->save_contacts(step, _contacts[r].accumulate()); _contacts[r].clear(); }
+            if (step % _config.contactmap_update_interval == 0 && _contact_distance > 0)     // (the reference's distance is 0 until callback(0) has set it)
+                chk(gd_contacts_update(_sys, _contact_distance));
+            if (sampling && frame % _config.contactmap_thinning_rate == 0) {
+                for (std::size_t r = 0; r < _R; r++) _stores[r]->save_contacts(step, fetch_contacts(_sys, (uint32_t)r));
+                chk(gd_contacts_clear(_sys, GD_ALL_REPLICAS));
+            }
         };
 
         // callback(0): observation, then update_bead_scale() and update_wall_semiaxes() on the host
@@ -245,7 +229,7 @@ private:
             auto &c = _context[r];
             c.bead_scale = 1 - (1 - _config.bead_scale_init) * std::exp(-0.0 / _config.bead_scale_tau);
             c.bond_scale = 1 - (1 - _config.bond_scale_init) * std::exp(-0.0 / _config.bond_scale_tau);
-            _contacts[r].set_contact_distance(_config.contactmap_distance * c.bead_scale);
+            _contact_distance = _config.contactmap_distance * c.bead_scale;
             for (int k = 0; k < 3; k++)
                 c.wall_semiaxes[k] += dt * _config.wall_mobility * (reaction[r][k] - spring[k] * c.wall_semiaxes[k]);
             chk(gd_set_context(_sys, (uint32_t)r, 0, c.bead_scale, c.bond_scale, c.wall_semiaxes));
@@ -273,7 +257,7 @@ private:
     std::size_t _R;
     gd::simulation_config _config;
     std::vector<gd::context> _context;
-    std::vector<contact_map> _contacts;
+    double _contact_distance = 0;
     std::vector<std::mt19937_64> _random;
     gd_system *_sys = nullptr;
     std::size_t _n = 0;

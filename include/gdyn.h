@@ -289,6 +289,22 @@ int gd_compute_forces(gd_system *sys, uint32_t term_mask, double *forces);
 int gd_search_pairs(gd_system *sys, uint32_t replica, double dcut,
                     uint32_t *pairs, uint64_t cap, uint64_t *n_pairs);
 
+/* contact_map (5-sim-genome/src/simulation_interphase/contact_map.hpp, contact_map.cc:26-91): the time-integrated contact map
+ * of EVERY replica of the handle, kept on the device between two dumps.
+ *   gd_contacts_update(distance)   contact_map::update(points) (contact_map.cc:31-74; call site
+ *                                  simulation_driver_interphase.cc:33-35) for all replicas at once: every unique pair i<j within
+ *                                  `distance` (the handle's box decides the metric, as for gd_search_pairs) is counted once more.
+ *                                  One pair search over all replicas + one insert launch; the pairs never leave the device.
+ *   gd_contacts_fetch(replica,...) contact_map::accumulate() (:77-91; simulation_driver_interphase.cc:37-38): rows (i, j, count),
+ *                                  count > 0, in row-major order (i ascending, then j); writes up to cap rows of three
+ *                                  uint32, returns the total in *n_rows (rows == NULL, cap == 0: the count only, free).
+ *   gd_contacts_clear(replica)     contact_map::clear() (:26-29) of one replica, or of all (GD_ALL_REPLICAS).
+ * The map is keyed by bead index and survives gd_set_positions / gd_begin_phase; gd_destroy frees it. */
+#define GD_ALL_REPLICAS 0xffffffffu
+int gd_contacts_update(gd_system *sys, double distance);
+int gd_contacts_fetch(gd_system *sys, uint32_t replica, uint32_t *rows, uint64_t cap, uint64_t *n_rows);
+int gd_contacts_clear(gd_system *sys, uint32_t replica);
+
 /* --------------------------------------------------------- tuning / timing */
 
 typedef struct {

@@ -100,6 +100,8 @@ struct gd_system {
     double *vl_rv;       /* list radius at build */
     uint64_t rebuilds, visited;
     gd_timing timing;
+    /* contact maps: per replica the non-zeros of the count matrix as (i << 32 | j, count), sorted by key = row-major order */
+    uint64_t **cm_key; uint32_t **cm_val; uint64_t *cm_n;
 };
 
 /* ----------------------------------------------------------------- utilities */
@@ -268,6 +270,7 @@ int gd_destroy(gd_system *s)
     if (!s) return GD_OK;
     for (uint32_t r = 0; r < s->R; r++) { free(s->vl_start[r]); free(s->vl_idx[r]); free(s->vl_x0[r]); }
     free(s->vl_start); free(s->vl_idx); free(s->vl_x0); free(s->vl_rv);
+    if (s->cm_key) { for (uint32_t r = 0; r < s->R; r++) { free(s->cm_key[r]); free(s->cm_val[r]); } free(s->cm_key); free(s->cm_val); free(s->cm_n); }
     for (int i = 0; i < MAX_DYN; i++) free(s->dyn[i].pairs);
     for (int i = 0; i < s->nps; i++) free(s->ps[i].mask);
     free(s->x); free(s->a); free(s->b); free(s->mob); free(s->bend);
@@ -640,6 +643,63 @@ int gd_search_pairs(gd_system *s, uint32_t r, double dcut, uint32_t *pairs, uint
     collect_t c = { pairs, cap, 0 };
     enum_pairs(s, s->x + (size_t)r * s->N * 3, dcut, collect_cb, &c);
     *n_pairs = c.n;
+    return GD_OK;
+}
+
+/* ------------------------------------------------------------- contact maps
+ * contact_map.cc:31-74: update() turns the pairs within the contact distance into a 0/1 sparse matrix and adds it to the count
+ * matrix; :77-91: accumulate() walks the count matrix row by row; :26-29: clear() empties it.  Restated on a sorted key array. */
+
+typedef struct { uint64_t *key; uint64_t cap, n; } keys_t;
+static void keys_cb(void *ud, uint32_t i, uint32_t j)
+{
+    keys_t *k = ud;
+    if (k->n == k->cap) { k->cap = k->cap ? 2 * k->cap : 1024; k->key = realloc(k->key, k->cap * sizeof(uint64_t)); if (!k->key) abort(); }
+    k->key[k->n++] = ((uint64_t)i << 32) | j;
+}
+static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
+
+int gd_contacts_update(gd_system *s, double distance)
+{
+    if (!s) return fail(GD_EINVAL, "gd_contacts_update: NULL argument");
+    if (!(distance > 0)) return fail(GD_EINVAL, "gd_contacts_update: the contact distance must be positive");
+    if (!s->cm_key) { s->cm_key = xcalloc(s->R, sizeof *s->cm_key); s->cm_val = xcalloc(s->R, sizeof *s->cm_val); s->cm_n = xcalloc(s->R, sizeof *s->cm_n); }
+    for (uint32_t r = 0; r < s->R; r++) {
+        keys_t k = { NULL, 0, 0 };
+        enum_pairs(s, s->x + (size_t)r * s->N * 3, distance, keys_cb, &k);
+        qsort(k.key, k.n, sizeof(uint64_t), cmp_u64);
+        /* count matrix += 0/1 matrix: merge of two sorted key arrays */
+        uint64_t na = s->cm_n[r], nb = k.n, n = 0, ia = 0, ib = 0;
+        uint64_t *ok = xcalloc(na + nb + 1, sizeof(uint64_t)); uint32_t *ov = xcalloc(na + nb + 1, sizeof(uint32_t));
+        while (ia < na || ib < nb) {
+            if (ib == nb || (ia < na && s->cm_key[r][ia] < k.key[ib])) { ok[n] = s->cm_key[r][ia]; ov[n++] = s->cm_val[r][ia++]; }
+            else if (ia == na || k.key[ib] < s->cm_key[r][ia]) { ok[n] = k.key[ib++]; ov[n++] = 1; }
+            else { ok[n] = k.key[ib++]; ov[n++] = s->cm_val[r][ia++] + 1; }
+        }
+        free(s->cm_key[r]); free(s->cm_val[r]); free(k.key);
+        s->cm_key[r] = ok; s->cm_val[r] = ov; s->cm_n[r] = n;
+    }
+    return GD_OK;
+}
+
+int gd_contacts_fetch(gd_system *s, uint32_t r, uint32_t *rows, uint64_t cap, uint64_t *n_rows)
+{
+    if (!s || !n_rows || (cap && !rows)) return fail(GD_EINVAL, "gd_contacts_fetch: NULL argument");
+    if (r >= s->R) return fail(GD_EINVAL, "gd_contacts_fetch: bad replica");
+    uint64_t n = s->cm_key ? s->cm_n[r] : 0;
+    for (uint64_t k = 0; k < n && k < cap; k++) {
+        rows[3 * k] = (uint32_t)(s->cm_key[r][k] >> 32); rows[3 * k + 1] = (uint32_t)s->cm_key[r][k]; rows[3 * k + 2] = s->cm_val[r][k];
+    }
+    *n_rows = n;
+    return GD_OK;
+}
+
+int gd_contacts_clear(gd_system *s, uint32_t r)
+{
+    if (!s) return fail(GD_EINVAL, "gd_contacts_clear: NULL argument");
+    if (r != GD_ALL_REPLICAS && r >= s->R) return fail(GD_EINVAL, "gd_contacts_clear: bad replica");
+    if (!s->cm_key) return GD_OK;
+    for (uint32_t k = 0; k < s->R; k++) if (r == GD_ALL_REPLICAS || r == k) s->cm_n[k] = 0;
     return GD_OK;
 }
 

@@ -259,6 +259,34 @@ def test_neighbor_search_equals_bruteforce(oracle, box):
     assert cells == brute and len(brute) > 100
 
 
+def test_contact_map_counts_equal_dense_accumulation(oracle):
+    """contact_map::update / accumulate / clear (contact_map.cc:26-91): after several updates on different structures the rows
+    are the non-zeros of the summed 0/1 matrices of the pairs within the distance, in row-major order; clear() empties one map."""
+    rng = np.random.default_rng(8)
+    n, R = 400, 2
+    s = g.System(oracle, n, R)
+    dense = np.zeros((R, n, n), dtype=np.int64)
+    assert s.contacts(0).shape == (0, 3)
+    for k, dist in enumerate((0.3, 0.3, 0.45)):
+        x = rng.random((R, n, 3)) * 2.0
+        s.set_positions(x)
+        s.contacts_update(dist)
+        for r in range(R):
+            d = np.linalg.norm(x[r][:, None] - x[r][None], axis=2)
+            dense[r] += np.triu(d < dist, 1)
+    for r in range(R):
+        rows = s.contacts(r)
+        i, j = np.nonzero(dense[r])                    # row-major order
+        assert np.array_equal(rows[:, 0], i) and np.array_equal(rows[:, 1], j) and np.array_equal(rows[:, 2], dense[r][i, j])
+        assert rows[:, 2].max() >= 2
+    s.contacts_clear(1)
+    assert len(s.contacts(1)) == 0 and len(s.contacts(0)) == np.count_nonzero(dense[0])
+    s.contacts_clear()
+    assert len(s.contacts(0)) == 0
+    with pytest.raises(RuntimeError):
+        s.contacts_update(0.0)
+
+
 def test_verlet_list_trajectory_equals_bruteforce(oracle):
     out = []
     for brute in (1, 0):

@@ -117,6 +117,49 @@ def test_replica_seeds_match_oracle(hip, oracle, path):
     assert np.abs(out[1][0] - out[1][1]).max() > 1e-4
 
 
+@pytest.mark.parametrize("box", [None, (2.9,) * 3])
+def test_contact_map_equals_oracle(hip, oracle, box):
+    """gd_contacts_*: the device tables (insert, growth by rehash, dump through the radix sort, clear) against the oracle's sorted
+    merge over several updates of several replicas; rows identical except for pairs within fp32 rounding of the distance."""
+    rng = np.random.default_rng(12)
+    n, R = 1500, 3
+    sh, so = g.System(hip, n, R, box=box), g.System(oracle, n, R, box=box)
+    near = {}                                            # pairs that may legitimately differ, per replica
+    for k, dist in enumerate((0.3, 0.3, 0.22, 0.36, 0.3)):
+        x = (rng.random((R, n, 3)) * (np.array(box) if box else 3.0) * (0.6 if k == 2 else 1.0)).astype(np.float32).astype(np.float64)
+        if k == 1:
+            x[1] = xprev[1]                              # replica 1 stands still once: its counts reach 2 everywhere
+        xprev = x
+        for s in (sh, so):
+            s.set_positions(x)
+            s.contacts_update(dist)
+        for r in range(R):
+            ph = {tuple(p) for p in sh.search_pairs(dist, replica=r)}
+            so1 = g.System(oracle, n, 1, box=box); so1.set_positions(x[r][None])
+            near.setdefault(r, set()).update(ph ^ {tuple(p) for p in so1.search_pairs(dist)})
+    total = 0
+    for r in range(R):
+        rh, ro = sh.contacts(r), so.contacts(r)
+        kh = {(int(a), int(b)): int(c) for a, b, c in rh}
+        ko = {(int(a), int(b)): int(c) for a, b, c in ro}
+        assert len(kh) == len(rh) and np.all(rh[:, 0] < rh[:, 1])
+        key = rh[:, 0].astype(np.uint64) << np.uint64(32) | rh[:, 1].astype(np.uint64)
+        assert np.all(np.diff(key.astype(np.int64)) > 0)                   # row-major order, no duplicates
+        for pr in set(kh) | set(ko):
+            if kh.get(pr, 0) != ko.get(pr, 0):
+                assert pr in near[r] and abs(kh.get(pr, 0) - ko.get(pr, 0)) <= 1
+        total += len(rh)
+    assert total > 20000 and max(c for c in kh.values()) >= 1
+    assert max(int(c) for c in sh.contacts(1)[:, 2]) >= 2
+    sh.contacts_clear(0); so.contacts_clear(0)
+    assert len(sh.contacts(0)) == 0 and len(so.contacts(0)) == 0 and abs(len(sh.contacts(2)) - len(so.contacts(2))) <= len(near[2])
+    sh.contacts_clear()
+    assert all(len(sh.contacts(r)) == 0 for r in range(R))
+    x = (rng.random((R, n, 3)) * (np.array(box) if box else 3.0)).astype(np.float32).astype(np.float64)
+    sh.set_positions(x); sh.contacts_update(0.3)
+    assert len(sh.contacts(0)) == len(sh.search_pairs(0.3, replica=0))     # a cleared map counts again
+
+
 @pytest.mark.parametrize("box", [None, (2.9,) * 3, (0.9, 1.3, 2.9)])
 def test_neighbor_search_pair_set(hip, oracle, box):
     """md::neighbor_searcher::search: the pair SET is exact (beads on cell/box boundaries, aliasing small grids)."""
