@@ -94,12 +94,13 @@ inline simulation_config parse_simulation_config(std::string const &text)
     return c;
 }
 
-// Two stored configurations describe the same model and schedule: every entry except the two seeds agrees (the batched
-// driver runs R prepared files as R replicas of ONE handle, i.e. one force field, one cadence).
+// Two stored configurations describe the same model and schedule: every entry except the seeds agrees -- the master seed a
+// file was prepared with and the two seeds derived from it (prepare/run.py:46-55); the batched driver runs R prepared files
+// as R replicas of ONE handle, i.e. one force field, one cadence.
 inline bool same_model_config(std::string const &text_a, std::string const &text_b)
 {
     auto a = nlohmann::json::parse(text_a), b = nlohmann::json::parse(text_b);
-    for (char const *seed : {"spindle_seed", "interphase_seed"}) { a.erase(seed); b.erase(seed); }
+    for (char const *seed : {"seed", "spindle_seed", "interphase_seed"}) { a.erase(seed); b.erase(seed); }
     return a == b;
 }
 

@@ -13,6 +13,8 @@
 //   gd_h5tool contacts <file> <phase> <step>           prints "i j count" rows
 //   gd_h5tool dataset <file> <path> <out.f64>          any numeric dataset as raw doubles; prints its shape
 //   gd_h5tool strings <file> <path>                    a string dataset (scalar or 1-d), one item per line
+//   gd_h5tool packed-check <file> <rows>               the same (rows,3) uint32 and float arrays written by the library's filter pipeline and
+//        as hand-packed chunks on a thread pool (gd_h5util.hpp, gd_async_io.hpp); reads both back, compares values, chunking and filters
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -22,6 +24,7 @@
 
 #include <hdf5.h>
 
+#include "gd_async_io.hpp"
 #include "gd_store.hpp"
 
 static std::vector<char> slurp(std::string const &path)
@@ -187,6 +190,42 @@ int main(int argc, char **argv)
             std::ofstream out(argv[4], std::ios::binary);
             out.write(reinterpret_cast<char const *>(v.data()), (std::streamsize)(count * sizeof(double)));
             return 0;
+        }
+        if (cmd == "packed-check" && argc == 4) {
+            using namespace gd::h5;
+            std::size_t const rows = std::stoul(argv[3]);
+            std::vector<std::uint32_t> u(3 * rows);
+            std::vector<float> x(3 * rows);
+            for (std::size_t i = 0; i < 3 * rows; i++) { u[i] = (std::uint32_t)((i * 2654435761u) >> (i % 13)); x[i] = (float)((double)((i * 40503u) % 1000003u) / 65536.0); }
+            hid_t f = H5Fcreate(argv[2], H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+            if (f < 0) throw std::runtime_error("cannot create the file");
+            gd::thread_pool pool(gd::usable_threads(8));
+            auto pu = plan_packed(rows, 3, sizeof(std::uint32_t)), px = plan_packed(rows, 3, sizeof(float));
+            pool.parallel_for(pu.chunk_count(), [&](std::size_t c) { pack_chunk(pu, c, u.data()); });
+            pool.parallel_for(px.chunk_count(), [&](std::size_t c) { pack_chunk(px, c, x.data()); });
+            { hid a(write_array<std::uint32_t>(f, "u_lib", u.data(), rows, 3, H5T_NATIVE_UINT32, H5T_STD_U32LE)), b(write_packed_array(f, "u_packed", pu, H5T_STD_U32LE)); }
+            { hid a(write_array<float>(f, "x_lib", x.data(), rows, 3, H5T_NATIVE_FLOAT, H5T_IEEE_F32LE)), b(write_packed_array(f, "x_packed", px, H5T_IEEE_F32LE)); }
+            H5Fclose(f);
+            f = H5Fopen(argv[2], H5F_ACC_RDONLY, H5P_DEFAULT);
+            auto same_layout = [&](char const *a, char const *b) {
+                hid da(H5Dopen2(f, a, H5P_DEFAULT)), db(H5Dopen2(f, b, H5P_DEFAULT));
+                hid pa(H5Dget_create_plist(da)), pb(H5Dget_create_plist(db));
+                hsize_t ca[2] = {0, 0}, cb[2] = {0, 0};
+                if (rows && (H5Pget_chunk(pa, 2, ca) != 2 || H5Pget_chunk(pb, 2, cb) != 2 || ca[0] != cb[0] || ca[1] != cb[1])) return false;
+                if (H5Pget_nfilters(pa) != H5Pget_nfilters(pb)) return false;
+                for (int k = 0; k < H5Pget_nfilters(pa); k++) {
+                    unsigned fa, fb, va[4] = {0}, vb[4] = {0}; size_t na = 4, nb = 4;
+                    if (H5Pget_filter2(pa, (unsigned)k, &fa, &na, va, 0, nullptr, nullptr) != H5Pget_filter2(pb, (unsigned)k, &fb, &nb, vb, 0, nullptr, nullptr)) return false;
+                    if (na != nb || (na && va[0] != vb[0])) return false;
+                }
+                return true;
+            };
+            std::size_t n = 0;
+            bool ok = read_array<std::uint32_t>(f, "u_lib", 3, H5T_NATIVE_UINT32, &n) == u && read_array<std::uint32_t>(f, "u_packed", 3, H5T_NATIVE_UINT32, &n) == u &&
+                      read_array<float>(f, "x_lib", 3, H5T_NATIVE_FLOAT, &n) == x && read_array<float>(f, "x_packed", 3, H5T_NATIVE_FLOAT, &n) == x &&
+                      same_layout("u_lib", "u_packed") && same_layout("x_lib", "x_packed");
+            std::cout << (ok ? "packed-check ok " : "packed-check FAILED ") << rows << " rows, " << pu.chunk_count() << " chunks\n";
+            return ok ? 0 : 1;
         }
         if (cmd == "strings" && argc == 4) {
             hid_t f = H5Fopen(argv[2], H5F_ACC_RDONLY, H5P_DEFAULT);

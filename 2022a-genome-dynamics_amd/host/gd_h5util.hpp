@@ -3,7 +3,10 @@
 #pragma once
 #include <hdf5.h>
 
+#include <zlib.h>
+
 #include <algorithm>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -100,6 +103,66 @@ hid_t write_array(hid_t loc, std::string const &name, T const *data, std::size_t
     hid_t ds = H5Dcreate2(loc, name.c_str(), file_type, space, H5P_DEFAULT, props, H5P_DEFAULT);
     check(ds >= 0, "cannot create " + name);
     if (rows > 0) check(H5Dwrite(ds, mem_type, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) >= 0, "cannot write " + name);
+    return ds;
+}
+
+// The same dataset written in two steps, so that the expensive one needs no HDF5 call and can run on any thread:
+//   pack_chunk         one chunk through the dataset's filter pipeline by hand -- the byte shuffle of H5Z_FILTER_SHUFFLE (byte b of
+//                      every element, plane after plane), then deflate level 6 as H5Z_FILTER_DEFLATE stores it (a zlib stream);
+//                      the last chunk of a dataset is padded to the full chunk size with zeros, as the library does;
+//   write_packed_array the dataset with write_array's creation properties, its chunks handed to the file as they are
+//                      (H5Dwrite_chunk, filter mask 0 = every filter applied): readers decode them like any other chunk.
+// A batched driver writes R trajectory files at every snapshot; deflate is ~25 ms per MiB on one core and the HDF5 library is
+// not re-entrant, so the chunks are packed by a pool of threads and only the cheap part stays serial (gd_async_io.hpp).
+struct packed_array {
+    std::size_t rows = 0, cols = 0, chunk_rows = 0, elem = 0;
+    std::vector<std::vector<unsigned char>> chunks;
+    std::size_t chunk_count() const { return rows ? (rows + chunk_rows - 1) / chunk_rows : 0; }
+};
+
+inline packed_array plan_packed(std::size_t rows, std::size_t cols, std::size_t elem)
+{
+    packed_array p;
+    p.rows = rows; p.cols = cols; p.elem = elem;
+    p.chunk_rows = rows ? std::min<std::size_t>((1024 * 1024) / (elem * cols), rows) : 0;
+    p.chunks.resize(p.chunk_count());
+    return p;
+}
+
+inline void pack_chunk(packed_array &p, std::size_t c, void const *data)      // data: the whole (rows, cols) array
+{
+    std::size_t const row_bytes = p.cols * p.elem, chunk_bytes = p.chunk_rows * row_bytes;
+    std::size_t const first = c * p.chunk_rows, valid = std::min(p.chunk_rows, p.rows - first) * row_bytes;
+    std::vector<unsigned char> shuffled(chunk_bytes, 0);
+    unsigned char const *src = static_cast<unsigned char const *>(data) + first * row_bytes;
+    std::size_t const n = chunk_bytes / p.elem, nvalid = valid / p.elem;
+    for (std::size_t b = 0; b < p.elem; b++) {
+        unsigned char *plane = shuffled.data() + b * n;
+        for (std::size_t i = 0; i < nvalid; i++) plane[i] = src[i * p.elem + b];
+    }
+    uLongf size = compressBound((uLong)chunk_bytes);
+    p.chunks[c].resize(size);
+    if (compress2(p.chunks[c].data(), &size, shuffled.data(), (uLong)chunk_bytes, 6) != Z_OK) throw h5_error("hdf5: deflate failed");
+    p.chunks[c].resize(size);
+}
+
+inline hid_t write_packed_array(hid_t loc, std::string const &name, packed_array const &p, hid_t file_type)
+{
+    unlink_if_present(loc, name);
+    hsize_t dims[2] = {p.rows, p.cols};
+    hid space(H5Screate_simple(2, dims, nullptr)), props(H5Pcreate(H5P_DATASET_CREATE));
+    if (p.rows > 0) {
+        hsize_t chunk[2] = {p.chunk_rows, p.cols};
+        H5Pset_chunk(props, 2, chunk);
+        H5Pset_shuffle(props);
+        H5Pset_deflate(props, 6);
+    }
+    hid_t ds = H5Dcreate2(loc, name.c_str(), file_type, space, H5P_DEFAULT, props, H5P_DEFAULT);
+    check(ds >= 0, "cannot create " + name);
+    for (std::size_t c = 0; c < p.chunk_count(); c++) {
+        hsize_t offset[2] = {c * p.chunk_rows, 0};
+        check(H5Dwrite_chunk(ds, H5P_DEFAULT, 0, offset, p.chunks[c].size(), p.chunks[c].data()) >= 0, "cannot write a chunk of " + name);
+    }
     return ds;
 }
 

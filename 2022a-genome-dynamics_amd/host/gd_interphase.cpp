@@ -13,18 +13,24 @@
 // (nucleolus_droplet_energy != 0) uses a documented choice of micromd's potential form (include/gdyn.h).
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <ctime>
 #include <iomanip>
 #include <iostream>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gdyn.h"
+#include "gd_async_io.hpp"
 #include "gd_config.hpp"
 #include "gd_genome_model.hpp"
 #include "gd_store.hpp"
@@ -32,6 +38,30 @@
 namespace {
 
 using gd::chk;
+
+// --timing: where the wall time of a run goes (stepping thread and writer thread), one line on stderr at the end
+class timing_table {
+public:
+    struct scope {
+        timing_table &t; char const *name; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~scope() { t.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    };
+    void add(char const *name, double seconds) { std::lock_guard<std::mutex> lk(_m); _t[name] += seconds; }
+    void note(std::string const &line) { std::lock_guard<std::mutex> lk(_m); _notes.push_back(line); }
+    void print() const
+    {
+        for (auto const &n : _notes) std::clog << "[timing] " << n << '\n';
+        std::clog << "[timing]";
+        for (auto const &kv : _t) std::clog << ' ' << kv.first << ' ' << std::fixed << std::setprecision(3) << kv.second;
+        std::clog << '\n';
+    }
+private:
+    std::mutex _m;
+    std::map<std::string, double> _t;
+    std::vector<std::string> _notes;
+};
+timing_table g_timing;
+#define TIMED(name) timing_table::scope timed_scope_##__LINE__{g_timing, name}
 
 // Time-integrated contact maps (simulation_interphase/contact_map.cc:26-91) live on the device, one per replica (gd_contacts_*):
 // an update is one pair search over all replicas plus one insert launch, and only a dump moves rows to the host.
@@ -67,11 +97,27 @@ public:
                 throw std::runtime_error("batched trajectories must share one simulation config (seeds aside)");
             _random.emplace_back(cfg.interphase_seed);          // 1st draw: relaxation seed, 2nd: interphase seed
         }
+        TIMED("setup");
         setup(device);
     }
     ~simulation_driver() { gd_destroy(_sys); }
 
-    void run() { run_relaxation(); run_simulation(); }
+    void run()
+    {
+        run_relaxation(); report("relaxation"); run_simulation(); report("interphase");
+        TIMED("writer_wait");
+        _writer.drain();
+    }
+    void report(char const *phase)      // (--timing) the list statistics of the handle at the end of a phase
+    {
+        gd_context c;
+        chk(gd_get_context(_sys, 0, &c));
+        char line[256];
+        std::snprintf(line, sizeof line, "%s: list path %u, %.1f entries per bead, radius %.4f, interval %u, %llu builds, %llu rollbacks",
+                      phase, c.list_path, (double)c.list_entries / (double)_n, c.list_radius, c.rebuild_interval,
+                      (unsigned long long)c.rebuilds, (unsigned long long)c.rollbacks);
+        g_timing.note(line);
+    }
 
 private:
     void setup(int device)
@@ -126,17 +172,61 @@ private:
 
     void mean_energy()
     {
+        TIMED("energy");
         chk(gd_compute_energy(_sys, GD_TERM_ALL, _energy.data()));
         for (std::size_t r = 0; r < _R; r++) _context[r].mean_energy = _energy[r] / (double)_n;
     }
 
+    // Output leaves the stepping thread as a job (gd_async_io.hpp): the chunks of all R files are packed on the pool's threads, the
+    // HDF5 calls follow on the writer thread, the device goes on stepping meanwhile.
     void save_snapshot(long step)
     {
-        chk(gd_get_positions_f32(_sys, _buffer.data(), /*quantize=*/1));      // 16 fractional bits, rounded on the device
-        for (std::size_t r = 0; r < _R; r++) {
-            _stores[r]->save_positions(step, _buffer.data() + 3 * _n * r, _n);
-            _stores[r]->save_context(step, _context[r]);
+        std::shared_ptr<std::vector<float>> xyz;
+        {
+            TIMED("snapshot_download");
+            chk(gd_get_positions_f32(_sys, _buffer.data(), /*quantize=*/1));      // 16 fractional bits, rounded on the device
+            xyz = std::make_shared<std::vector<float>>(_buffer);
         }
+        auto ctx = std::make_shared<std::vector<gd::context>>(_context);
+        TIMED("writer_wait");
+        _writer.submit([this, step, xyz, ctx] {
+            std::vector<gd::h5::packed_array> packed(_R, gd::h5::plan_packed(_n, 3, sizeof(float)));
+            std::size_t const per = packed[0].chunk_count();
+            {
+                TIMED("w:pack");
+                _pool.parallel_for(_R * per, [&](std::size_t t) { gd::h5::pack_chunk(packed[t / per], t % per, xyz->data() + 3 * _n * (t / per)); });
+            }
+            TIMED("w:hdf5");
+            for (std::size_t r = 0; r < _R; r++) {
+                _stores[r]->save_positions_packed(step, packed[r]);
+                _stores[r]->save_context(step, (*ctx)[r]);
+            }
+        });
+    }
+
+    void save_contacts(long step)
+    {
+        auto rows = std::make_shared<std::vector<std::vector<std::array<std::uint32_t, 3>>>>(_R);
+        {
+            TIMED("contacts_fetch");
+            for (std::size_t r = 0; r < _R; r++) (*rows)[r] = fetch_contacts(_sys, (uint32_t)r);
+            chk(gd_contacts_clear(_sys, GD_ALL_REPLICAS));
+        }
+        TIMED("writer_wait");
+        _writer.submit([this, step, rows] {
+            std::vector<gd::h5::packed_array> packed(_R);
+            std::vector<std::pair<std::size_t, std::size_t>> tasks;
+            for (std::size_t r = 0; r < _R; r++) {
+                packed[r] = gd::h5::plan_packed((*rows)[r].size(), 3, sizeof(std::uint32_t));
+                for (std::size_t c = 0; c < packed[r].chunk_count(); c++) tasks.push_back({r, c});
+            }
+            {
+                TIMED("w:pack");
+                _pool.parallel_for(tasks.size(), [&](std::size_t t) { gd::h5::pack_chunk(packed[tasks[t].first], tasks[t].second, (*rows)[tasks[t].first].data()); });
+            }
+            TIMED("w:hdf5");
+            for (std::size_t r = 0; r < _R; r++) _stores[r]->save_contacts_packed(step, packed[r]);
+        });
     }
 
     // advance to `target` and leave the state updates of callback(target) pending (GD_RUN_DEFER_CALLBACK): what the host
@@ -146,7 +236,7 @@ private:
     void advance(gd_run_desc &run, long &step, long target)
     {
         run.steps = target - step; run.flags |= GD_RUN_DEFER_CALLBACK;
-        chk(gd_run(_sys, &run));
+        { TIMED("gd_run"); chk(gd_run(_sys, &run)); }
         for (std::size_t r = 0; r < _R; r++) {
             gd_context ctx;
             chk(gd_get_context(_sys, (uint32_t)r, &ctx));
@@ -186,7 +276,7 @@ private:
         while (step < _config.relaxation_steps) {
             long const next = std::min<long>(_config.relaxation_steps, std::min(next_multiple(step, _config.relaxation_logging_interval),
                                                                                 next_multiple(step, _config.relaxation_sampling_interval)));
-            run.steps = next - step; chk(gd_run(_sys, &run)); step = next;
+            run.steps = next - step; { TIMED("gd_run"); chk(gd_run(_sys, &run)); } step = next;
             callback(step);
         }
     }
@@ -195,6 +285,7 @@ private:
 
     void run_simulation()
     {
+        { TIMED("writer_wait"); _writer.drain(); }          // (the relaxation's last snapshot goes to the relaxation phase)
         for (auto &st : _stores) st->set_phase("interphase");
         double const dt = _config.interphase_timestep;
         chk(gd_begin_phase(_sys, semiaxes().data()));       // step = 0, time = 0
@@ -213,12 +304,11 @@ private:
             if (logging || sampling) mean_energy();
             if (logging) print_progress("inter", step);
             if (sampling) save_snapshot(step);
-            if (step % _config.contactmap_update_interval == 0 && _contact_distance > 0)     // (the reference's distance is 0 until callback(0) has set it)
+            if (step % _config.contactmap_update_interval == 0 && _contact_distance > 0) {   // (the reference's distance is 0 until callback(0) has set it)
+                TIMED("contacts_update");
                 chk(gd_contacts_update(_sys, _contact_distance));
-            if (sampling && frame % _config.contactmap_thinning_rate == 0) {
-                for (std::size_t r = 0; r < _R; r++) _stores[r]->save_contacts(step, fetch_contacts(_sys, (uint32_t)r));
-                chk(gd_contacts_clear(_sys, GD_ALL_REPLICAS));
             }
+            if (sampling && frame % _config.contactmap_thinning_rate == 0) save_contacts(step);
         };
 
         // callback(0): observation, then update_bead_scale() and update_wall_semiaxes() on the host
@@ -262,6 +352,8 @@ private:
     gd_system *_sys = nullptr;
     std::size_t _n = 0;
     std::vector<float> _buffer;
+    gd::thread_pool _pool{gd::usable_threads()};
+    gd::async_writer _writer;      // (after the pool and the stores it uses: destroyed first)
     std::vector<double> _energy;
 };
 
@@ -273,9 +365,12 @@ int main(int argc, char **argv)
     // gd_interphase [--device d] <trajectory> <trajectory>...  R prepared files as R replicas of one handle
     std::vector<std::string> files;
     int device = 0;
+    bool timing = false;
+    auto const t_start = std::chrono::steady_clock::now();
     for (int i = 1; i < argc; i++) {
         std::string const arg = argv[i];
-        if (arg == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
+        if (arg == "--timing") timing = true;
+        else if (arg == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
         else files.push_back(arg);
     }
     if (files.size() == 2 && !files[1].empty() && files[1].find_first_not_of("0123456789") == std::string::npos) {
@@ -287,9 +382,17 @@ int main(int argc, char **argv)
     }
     try {
         std::vector<std::unique_ptr<gd::trajectory_store>> stores;
-        for (auto const &f : files) stores.push_back(std::make_unique<gd::trajectory_store>(f));
-        simulation_driver driver{stores, device};
-        driver.run();
+        {
+            TIMED("open_files");
+            for (auto const &f : files) stores.push_back(std::make_unique<gd::trajectory_store>(f));
+        }
+        {
+            simulation_driver driver{stores, device};
+            driver.run();
+        }
+        { TIMED("close_files"); stores.clear(); }
+        g_timing.add("total", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+        if (timing) g_timing.print();
     } catch (std::exception const &e) {
         std::cerr << "error: " << e.what() << '\n';
         return 1;

@@ -288,6 +288,21 @@ void trajectory_store::save_contacts(long step, std::vector<std::array<std::uint
     flush();
 }
 
+void trajectory_store::save_positions_packed(long step, h5::packed_array const &p)
+{
+    hid snap(snapshot_group(step));
+    hid(write_packed_array(snap, "positions", p, H5T_IEEE_F32LE));
+    flush();
+}
+
+void trajectory_store::save_contacts_packed(long step, h5::packed_array const &p)
+{
+    if (p.rows == 0) return;
+    hid snap(snapshot_group(step));
+    hid(write_packed_array(snap, "contact_map", p, H5T_STD_U32LE));
+    flush();
+}
+
 std::vector<std::array<double, 3>> trajectory_store::load_positions(long step)
 {
     hid snap(snapshot_group(step));

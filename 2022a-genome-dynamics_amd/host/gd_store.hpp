@@ -71,6 +71,9 @@ public:
     void save_positions(long step, double const *xyz, std::size_t n);               // quantises like simulation_store.cc:257-268
     void save_context(long step, context const &c);
     void save_contacts(long step, std::vector<std::array<std::uint32_t, 3>> const &contacts);
+    // the same datasets from chunks packed beforehand, possibly on other threads (gd_h5util.hpp: plan_packed / pack_chunk)
+    void save_positions_packed(long step, h5::packed_array const &p);
+    void save_contacts_packed(long step, h5::packed_array const &p);
     std::vector<std::array<double, 3>> load_positions(long step);
     context load_context(long step);
     std::vector<long> load_steps();

@@ -103,6 +103,19 @@ def _positions(tmp, phase, step):
     return np.fromfile(tmp / "out.f64", dtype="<f8").reshape(-1, 3)
 
 
+@pytest.mark.parametrize("rows", [0, 1, 5000, 87381, 87382, 400001])
+def test_hand_packed_chunks_read_back_like_the_library_pipeline(tmp_path, rows):
+    """Batched drivers deflate their chunks on a thread pool and hand them to the file as they are (H5Dwrite_chunk): the datasets
+    must read back exactly like ones written through the library's shuffle + deflate pipeline, with the same chunking and filter
+    list -- empty, one row, one partial chunk, exactly one 1 MiB chunk, one row more, several chunks with a padded last one."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "h5lib/libhdf5.so", "gd_h5tool"])
+    out = _tool("packed-check", tmp_path / "p.h5", rows)
+    assert out.startswith("packed-check ok")
+    if rows == 400001 and os.path.exists("/opt/conda/bin/h5dump"):
+        hdr = subprocess.check_output(["/opt/conda/bin/h5dump", "-H", "-p", str(tmp_path / "p.h5")], text=True)
+        assert hdr.count("COMPRESSION DEFLATE { LEVEL 6 }") == 4 and hdr.count("PREPROCESSING SHUFFLE") == 4
+
+
 def _python_driver(lib, oracle, cfg, a, b, x0q, ranges, droplet=False):
     """The same ABI call sequence as gd_interphase.cpp, issued from Python; returns {(phase, step): (positions, context)}."""
     s = g.System(lib, N, 1)

@@ -178,6 +178,27 @@ def test_pipeline_prepare_spindle_refine_interphase_on_oracle(tmp_path, oracle):
     assert sum(ln.startswith("[inter]") for ln in log.stderr.splitlines()) == 4
 
 
+def test_batched_interphase_takes_files_prepared_with_different_master_seeds(tmp_path, oracle):
+    """The reference's ensemble: `prepare --seed S` per run (scripts/run_simulation:8-25), so the stored configs differ in `seed`
+    and the two derived seeds and in nothing else -- such files batch into one handle; a file with another model does not."""
+    env = _env(os.path.join(ROOT, "oracle"))
+    spindle, interphase = _make_oracle("gd_spindle", tmp_path), _make_oracle("gd_interphase", tmp_path)
+    _write_genome(tmp_path / "genome.tsv", _toy_genome())
+    files = []
+    for k, (seed, over) in enumerate(((7, {}), (8, {}), (9, {"a_core_diameter": 0.31}))):
+        (tmp_path / f"config{k}.json").write_text(json.dumps(dict(_toy_config(), **over)))
+        f = tmp_path / f"output-{k}.h5"
+        _run(sys.executable, os.path.join(HOST, "gd_prepare.py"), "--seed", seed, tmp_path / f"config{k}.json", tmp_path / "genome.tsv", f)
+        _run(spindle, f, env=env)
+        _run(sys.executable, os.path.join(HOST, "gd_refine.py"), f)
+        files.append(f)
+    _run(interphase, files[0], files[1], env=env)
+    for f in files[:2]:
+        assert _tool("steps", f, "interphase").split() == ["0", "20", "40", "60"]
+    r = subprocess.run([str(interphase), str(files[0]), str(files[2])], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "share one simulation config" in r.stderr
+
+
 @pytest.mark.gpu
 def test_pipeline_on_gpu_matches_the_oracle_linked_pipeline(tmp_path, hip, oracle):
     env_o = _env(os.path.join(ROOT, "oracle"))
