@@ -146,6 +146,12 @@ private:
         c.wall_semiaxes[2] = _config.wall_init_semiaxes.z;
         c.bead_scale = _config.bead_scale_init; c.bond_scale = _config.bond_scale_init;
         _context.assign(_R, c);
+        {   // the list width follows the structure: a freshly refined genome is a dense globule (hundreds of list entries per bead
+            // at the default width) that decondenses over the run -- selected by the library from measured chunk times
+            gd_tuning tune{};
+            tune.adapt_interval = 1; tune.auto_skin = 1;
+            chk(gd_set_tuning(_sys, &tune));
+        }
         _buffer.resize(3 * _n * _R);
         _energy.resize(_R);
     }
