@@ -430,15 +430,15 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     }
     unsigned local = 0, nA = 0, nAq = 0, nB = 0;      // tiled: block-local slot of the thread's bead, chunks of the near and far class (nAq: near entries in fours)
     if (TILED) {
-        local = (mo.x >> 12) & 0x1ffu; nAq = (mo.x >> 21) & 63u; nA = (nAq + 1u) >> 1; nB = mo.x >> 27;
+        local = (mo.x >> 12) & 0x1ffu; nAq = mo.x >> 21; nA = (nAq + 1u) >> 1; nB = mo.y >> 26;
         meta = mo.x & 0xfffu;                    // degree | point-source mask << 8 (the generic layout without the length)
-        oid = mo.y;
+        oid = mo.y & GD_REC_ID_MASK;
     }
     // Brownian noise needs only (seed, bead, step, replica): it is generated here, while the tile DMAs
     // and the per-bead loads are in flight (the step index comes from a uniform scalar load).  Tiled path: whether the
     // thread owns a bead is not known yet (that is in the build-position record); threads without one have bead id 0.
     float3 z = make_float3(0.f, 0.f, 0.f);
-    if (MODE == GD_MODE_STEP && (TILED ? oid != GD_REC_NOBEAD : valid) && p.kT > 0.f) {
+    if (MODE == GD_MODE_STEP && (TILED ? oid != GD_REC_ID_MASK : valid) && p.kT > 0.f) {
         if (p.noise_mode == NOISE_PHILOX) {
             const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
             z = p.seeds ? philox_normal3(p.seeds[r], oid, step_now + 1, 0u) : philox_normal3(p.seed, oid, step_now + 1, r);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     __syncthreads();
     GD_STAMP(1);      // barrier (tile arrival)
     if (TILED) {
-        valid = oid != GD_REC_NOBEAD;
+        valid = oid != GD_REC_ID_MASK;
         slot = valid ? blk * GD_BLOCK + local : p.N;
         g = rbase + slot;
         if (valid) {
@@ -1611,28 +1611,28 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // the tiled record counts the chunks of EACH class in 5 bits: a class beyond 31 chunks does not fit it even when the
             // row is wide enough for the sum -- flagged like a row overflow, with a need beyond every tiled width (the host
             // then builds generic lists until the dense transient has passed)
-            const bool class_over = TILED && (needA > 31u * GD_UNROLL || needB > 31u * GD_UNROLL);
+            const bool class_over = TILED && (needA > GD_TILED_MAX_NEAR || needB > GD_TILED_MAX_FAR);
             if ((needw > p.W || (TILED && needw > GD_TILED_MAX_W) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
                 p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
                 atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], class_over ? max(needw, GD_TILED_MAX_W + 1u) : needw);
             }
             listlen = min(found, p.W);
-            nAq = min((cnt + 3u) / 4u, 62u);            // near entries in fours (the record's count; chunks are still written whole)
+            nAq = min((cnt + 3u) / 4u, GD_TILED_MAX_NEAR / 4u);            // near entries in fours (the record's count; chunks are still written whole)
             while (cnt % GD_UNROLL) push(self);
             flush();
             if (TILED) while (cntB % GD_UNROLL) push_far(self);
             // (an overflowed list is flagged and its chunk rolled back; the chunk counts still have to stay inside the row)
-            nAq = min(nAq, 2u * NC); nB = min(min(cntB / GD_UNROLL, 31u), NC - (nAq + 1u) / 2u);
+            nAq = min(nAq, 2u * NC); nB = min(min(cntB / GD_UNROLL, GD_TILED_MAX_FAR / GD_UNROLL), NC - (nAq + 1u) / 2u);
             cnt = found;
         }
         const unsigned meta = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
         if (TILED) {
             const float4 xb = rpos[slot];
             p.rec_x0[gt] = make_float4(xb.x, xb.y, xb.z, __uint_as_float(slot - blk * GD_BLOCK));
-            // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | near entries / 4 << 21 | far chunks << 27
-            // (at most 31 chunks per class: the host keeps the width of tiled lists <= GD_TILED_MAX_W), bead id (~0: no bead)
-            p.rec_mo[gt] = make_uint2(deg | (((unsigned)p.psmask_o[o] & 0xfu) << 8) | ((slot - blk * GD_BLOCK) << 12) | (nAq << 21) | (nB << 27), o);
-            p.len_prev[(size_t)r * p.N + o] = (unsigned char)nAq;       // (the near class is what most steps run over)
+            // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | near entries / 4 << 21, bead id | far chunks << 26
+            // (the host keeps the width of tiled lists <= GD_TILED_MAX_W; y all ones: no bead)
+            p.rec_mo[gt] = make_uint2(deg | (((unsigned)p.psmask_o[o] & 0xfu) << 8) | ((slot - blk * GD_BLOCK) << 12) | (nAq << 21), o | (nB << 26));
+            p.len_prev[(size_t)r * p.N + o] = (unsigned char)min(nAq, 255u);       // (the near class is what most steps run over)
         } else p.meta[g] = meta;
     }
     if (TILED && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
@@ -1781,8 +1781,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
     if (TILED) {
         const uint2 mo = p.rec_mo[gt];
         const unsigned local = (mo.x >> 12) & 0x1ffu;
-        nA = (((mo.x >> 21) & 63u) + 1u) >> 1;
-        valid = mo.y != GD_REC_NOBEAD; slot = blk * GD_BLOCK + (valid ? local : 0u); cnt = (nA + (mo.x >> 27)) * 8u;
+        nA = ((mo.x >> 21) + 1u) >> 1;
+        valid = mo.y != GD_REC_NOBEAD; slot = blk * GD_BLOCK + (valid ? local : 0u); cnt = (nA + (mo.y >> 26)) * 8u;
     } else if (valid) cnt = p.meta[rbase + slot] >> 16;
     const float4 *__restrict__ rpos = p.pos + rbase;
     float4 xi = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -25,8 +25,13 @@
 #define GD_CHAIN_LOCAL 0x40000000          // same for chain (bending) partners
 #define GD_TILE_RANGES 9                   // (dz,dy) rows of the 27-cell neighbourhood
 #define GD_XCDS 8
-#define GD_REC_NOBEAD 0xffffffffu          // tiled per-thread record: bead id of a thread without a bead
-#define GD_TILED_MAX_W 496u                 // tiled record: near entries in fours (6 bits) and far chunks (5 bits), at most 31 chunks of 8 per class
+#define GD_REC_NOBEAD 0xffffffffu          // tiled per-thread record: rec_mo.y of a thread without a bead
+// tiled per-thread record (rec_mo): x = bond degree | point-source mask << 8 | block-local slot << 12 | near entries / 4 << 21 (11 bits),
+// y = bead id (26 bits, like a bond partner) | far chunks << 26 (6 bits).  The classes are capped where the fields and a sane row end:
+#define GD_TILED_MAX_NEAR 1016u            // near entries (127 chunks of 8)
+#define GD_TILED_MAX_FAR 504u              // far entries (63 chunks)
+#define GD_TILED_MAX_W (GD_TILED_MAX_NEAR + GD_TILED_MAX_FAR)
+#define GD_REC_ID_MASK 0x03ffffffu         // bead id field of rec_mo.y; all ones = no bead
 #define GD_DMAX_STRIDE 32u                  // words between the replicas' displacement maxima: one 128-byte line each
 #define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 

@@ -316,7 +316,7 @@ typedef struct {
     uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
     uint32_t kernel_path;       /* 0 auto (LDS-tiled where the tiles fit, else generic), 1 generic (global-gather lists),
                                    2 LDS-tiled preferred: needs fp16-exact a/b factors, tiles that fit the LDS and rows of at most
-                                   496 entries; where that does not hold the build falls back to generic lists (a dense
+                                   1016 near + 504 far entries; where that does not hold the build falls back to generic lists (a dense
                                    transient) and retries later -- gd_context.list_path reports the path of the list in use */
     double   near_fraction;     /* tiled lists keep the entries closer than cutoff + near_fraction x skin width in a "near" class
                                    that every step walks, the rest in a "far" class that is walked only once displacements

@@ -707,13 +707,15 @@ def test_equilibrium_statistics_match_oracle(hip, oracle):
     assert np.allclose(ah, ao, rtol=2e-3)                   # the wall ODE integrates the same mean reaction
 
 
-def test_dense_cluster_beyond_the_tiled_record_falls_back(hip, oracle):
-    """A bead with more neighbours in ONE list class than the tiled record can count (31 chunks = 248 entries) while the row
-    is wide enough for the sum: the build must flag it and leave the tiled path, not clamp the chunk count (forces and
-    contact pairs would silently miss neighbours).  360 beads in a ball of radius 0.1 (every pair inside the near radius)
-    + a dilute background, list width 400, tiled path requested."""
+@pytest.mark.parametrize("n_core,width,path_expected", [(360, 400, 2), (1100, 1200, 1)])
+def test_dense_cluster_within_and_beyond_the_tiled_record(hip, oracle, n_core, width, path_expected):
+    """A ball of radius 0.1 in which every pair is inside the near radius + a dilute background, tiled path requested.
+    360 beads: 359 near entries per bead, more than the 248 a list class held before the record's count fields were widened
+    (11 bits of near entries in fours, 6 bits of far chunks) -- stays on the tiled path and matches the oracle.
+    1 100 beads: beyond the 1 016 near entries the record counts even though the row is wide enough -- the build must flag it
+    and leave the tiled path, not clamp the chunk count (forces and contact pairs would silently miss neighbours)."""
     rng = np.random.default_rng(11)
-    n_core, n = 360, 1200
+    n = n_core + 840
     v = rng.normal(size=(n_core, 3))
     core = 0.1 * v / np.linalg.norm(v, axis=1)[:, None] * rng.random((n_core, 1)) ** (1 / 3)
     x = np.concatenate([core, (rng.random((n - n_core, 3)) - 0.5) * 6.0]).astype(np.float32).astype(np.float64)
@@ -723,7 +725,7 @@ def test_dense_cluster_beyond_the_tiled_record_falls_back(hip, oracle):
         s.set_bead_params(a=(np.arange(n) % 2).astype(float), b=((np.arange(n) + 1) % 2).astype(float))
         s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
         if lib is hip:
-            s.set_tuning(kernel_path=2, list_width=400)
+            s.set_tuning(kernel_path=2, list_width=width)
         s.set_positions(x)
         out.append((s.forces(), s.energy(), {tuple(p) for p in s.search_pairs(0.3)}, s.context().list_path))
     (Fh, Eh, Ph, path), (Fo, Eo, Po, _) = out
@@ -732,7 +734,7 @@ def test_dense_cluster_beyond_the_tiled_record_falls_back(hip, oracle):
     for i, j in Ph ^ Po:
         assert abs(np.linalg.norm(x[i] - x[j]) - 0.3) < 1e-6
     assert len(Po) > n_core * (n_core - 1) // 2 - 10
-    assert path == 1          # generic lists: the tiled record cannot hold this bead
+    assert path == path_expected
 
 
 # ---------------------------------------------------------------- trajectories at scale, at the benchmark's cadence
