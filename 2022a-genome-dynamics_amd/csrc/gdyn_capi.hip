@@ -175,6 +175,8 @@ struct gd_system {
     DevBuf<uint2> ct_pairs; DevBuf<unsigned long long> ct_count; std::vector<unsigned> ct_distinct_h;
     DevBuf<unsigned long long> ct_ck[2]; DevBuf<unsigned> ct_cv[2], ct_n; DevBuf<char> ct_tmp;
     uint64_t state_serial = 1;     // bumped by everything that changes positions or the model (invalidates the cache)
+    uint64_t verified_serial = 0;  // == state_serial: the last gd_run ended on an accepted chunk, i.e. the resident list was verified for the
+                                   // positions and the cutoff an observation now sees (no bead beyond the skin margin): energies need no build
     int ocur = 0;   // which orig[] buffer is current
     std::vector<hipEvent_t> events;
     ~gd_system()
@@ -913,7 +915,7 @@ static float list_radius(gd_system *s, const gd_run_desc *run, uint32_t ahead)
 
 static int ensure_fresh_list(gd_system *s)
 {
-    if (s->list_valid && s->steps_since_build == 0) return GD_OK;
+    if (s->list_valid && (s->steps_since_build == 0 || s->verified_serial == s->state_serial)) return GD_OK;
     GDCHK(build_now(s, list_radius(s, nullptr, 0), pair_cutoff(s) > 0));
     s->list_valid = true; s->search_list = false;
     return GD_OK;
@@ -1225,6 +1227,12 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         if (with_list) tune_skin(s, ms, chunk, full_interval, false);
         done += chunk;
     }
+    // The last chunk was accepted: every bead is within the margin the list in use was built for, at the cutoff of the last step.
+    // That is still the cutoff an observation sees when the scales did not move behind that step (callback deferred, or no scale
+    // updates in this run) -- the resident list then serves gd_compute_energy as it is.
+    // (Not with the droplet term: its kernel moves beads behind k_step's check.)
+    if (run->steps > 0 && with_list && s->list_valid && !s->sw_n && (!(run->flags & GD_RUN_UPDATE_SCALES) || (run->flags & GD_RUN_DEFER_CALLBACK)))
+        s->verified_serial = s->state_serial;
     return GD_OK;
 }
 

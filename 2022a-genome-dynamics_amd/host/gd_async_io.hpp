@@ -16,8 +16,11 @@
 #include <condition_variable>
 #include <deque>
 #include <exception>
+#include <cstdlib>
+#include <fstream>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -157,15 +160,37 @@ private:
     std::thread _thread;      // (last: started when everything above exists)
 };
 
-// threads this process may use (its CPU affinity mask, not the machine's core count: a farm shares the host)
-inline unsigned usable_threads(unsigned at_most = 32)
+// CPUs this process may use: the smaller of its affinity mask and its cgroup's CPU quota (a farm shares the host; a container's
+// quota is usually far below the cores it can see, and threads beyond it only get the whole group throttled -- the stepping
+// thread included, whose stream synchronisations then stall for tens of milliseconds).
+inline unsigned usable_cpus()
 {
-    unsigned n = std::thread::hardware_concurrency();
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
 #ifdef __linux__
     cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    auto quota = [](char const *quota_file, char const *period_file) -> double {
+        std::ifstream q(quota_file);
+        std::string a, b;
+        if (!(q >> a)) return 0;
+        if (!period_file) { if (!(q >> b)) return 0; }                     // cgroup v2: "<quota|max> <period>"
+        else { std::ifstream p(period_file); if (!(p >> b)) return 0; }    // cgroup v1: two files
+        if (a == "max" || a == "-1") return 0;
+        double const period = std::atof(b.c_str());
+        return period > 0 ? std::atof(a.c_str()) / period : 0;
+    };
+    double c = quota("/sys/fs/cgroup/cpu.max", nullptr);
+    if (!(c > 0)) c = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (c > 0) n = std::min(n, std::max(1u, (unsigned)(c + 0.5)));
 #endif
-    return std::max(1u, std::min(n, at_most));
+    return n;
+}
+
+// threads for the packing pool: the usable CPUs less two (the stepping thread and the writer), at most `at_most`
+inline unsigned usable_threads(unsigned at_most = 16)
+{
+    unsigned const n = usable_cpus();
+    return std::max(1u, std::min(n > 2 ? n - 2 : 1u, at_most));
 }
 
 }  // namespace gd

@@ -104,12 +104,15 @@ public:
 
     void run()
     {
+        g_timing.note("packing pool of " + std::to_string(gd::usable_threads()) + " threads on " + std::to_string(gd::usable_cpus()) + " usable CPUs");
         run_relaxation(); report("relaxation"); run_simulation(); report("interphase");
         TIMED("writer_wait");
         _writer.drain();
     }
     void report(char const *phase)      // (--timing) the list statistics of the handle at the end of a phase
     {
+        g_timing.note(std::string(phase) + ": " + std::to_string(_energy_calls) + " energy evaluations so far, " + std::to_string(_energy_builds) +
+                      " list builds inside them, slowest " + std::to_string(_energy_max) + " s");
         gd_context c;
         chk(gd_get_context(_sys, 0, &c));
         char line[256];
@@ -179,7 +182,13 @@ private:
     void mean_energy()
     {
         TIMED("energy");
+        gd_context before, after;
+        chk(gd_get_context(_sys, 0, &before));
+        auto const t0 = std::chrono::steady_clock::now();
         chk(gd_compute_energy(_sys, GD_TERM_ALL, _energy.data()));
+        double const dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        chk(gd_get_context(_sys, 0, &after));
+        _energy_calls++; _energy_builds += after.rebuilds - before.rebuilds; _energy_max = std::max(_energy_max, dt);
         for (std::size_t r = 0; r < _R; r++) _context[r].mean_energy = _energy[r] / (double)_n;
     }
 
@@ -361,6 +370,8 @@ private:
     gd::thread_pool _pool{gd::usable_threads()};
     gd::async_writer _writer;      // (after the pool and the stores it uses: destroyed first)
     std::vector<double> _energy;
+    unsigned long _energy_calls = 0, _energy_builds = 0;
+    double _energy_max = 0;
 };
 
 }  // namespace

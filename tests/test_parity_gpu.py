@@ -707,6 +707,36 @@ def test_equilibrium_statistics_match_oracle(hip, oracle):
     assert np.allclose(ah, ao, rtol=2e-3)                   # the wall ODE integrates the same mean reaction
 
 
+def test_energy_after_a_deferred_run_uses_the_verified_resident_list(hip, oracle):
+    """The drivers observe after a GD_RUN_DEFER_CALLBACK run: an accepted chunk has verified the resident list for exactly the
+    positions and cutoff gd_compute_energy then sees, so it must not cost a list build -- and the energy must be the one a fresh
+    list gives (and the oracle's).  Without the deferral (scales moved behind the last step) the evaluation builds, as before."""
+    R = 4
+    s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    s.begin_phase()
+    s.run(300, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+    s.run(33, info["timestep"], info["temperature"], seed=SEED + 1, flags=flags | g.RUN_DEFER_CALLBACK)
+    b0 = s.context().rebuilds
+    e_resident = s.energy()
+    assert s.context().rebuilds == b0                     # no build for the observation
+    x = s.positions()
+    s2, _ = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)      # the same state on a fresh handle: its evaluation builds a list
+    s2.set_positions(x)
+    s2.begin_phase()
+    for r in range(R):
+        c = s.context(r)
+        s2.set_context(r, c.step, c.bead_scale, c.bond_scale, c.semiaxes)
+    e_fresh = s2.energy()
+    assert s2.context().rebuilds >= 1
+    assert np.abs(e_resident - e_fresh).max() <= 2e-6 * np.abs(e_fresh).max()
+    s.apply_callback()
+    s.run(20, info["timestep"], info["temperature"], seed=SEED + 2, flags=flags)      # no deferral: the scales moved behind the last step
+    b1 = s.context().rebuilds
+    s.energy()
+    assert s.context().rebuilds == b1 + 1
+
+
 @pytest.mark.parametrize("n_core,width,path_expected", [(360, 400, 2), (1100, 1200, 1)])
 def test_dense_cluster_within_and_beyond_the_tiled_record(hip, oracle, n_core, width, path_expected):
     """A ball of radius 0.1 in which every pair is inside the near radius + a dilute background, tiled path requested.
