@@ -81,8 +81,8 @@ std::vector<std::array<std::uint32_t, 3>> fetch_contacts(gd_system *sys, uint32_
 // (gd_run_desc.replica_seeds), so a batched trajectory equals the solo one up to fp32 summation order.
 class simulation_driver {
 public:
-    simulation_driver(std::vector<std::unique_ptr<gd::trajectory_store>> &stores, int device)
-        : _stores(stores), _R(stores.size()), _config(gd::parse_simulation_config(stores[0]->load_config_text()))
+    simulation_driver(std::vector<std::unique_ptr<gd::trajectory_store>> &stores, int device, bool auto_skin = true)
+        : _stores(stores), _R(stores.size()), _config(gd::parse_simulation_config(stores[0]->load_config_text())), _auto_skin(auto_skin)
     {
         // compatibility defaults of older runs (simulation_driver.cc:20-29)
         auto set_default = [](double &var, double def) { if (var == 0) var = def; };
@@ -152,7 +152,7 @@ private:
         {   // the list width follows the structure: a freshly refined genome is a dense globule (hundreds of list entries per bead
             // at the default width) that decondenses over the run -- selected by the library from measured chunk times
             gd_tuning tune{};
-            tune.adapt_interval = 1; tune.auto_skin = 1;
+            tune.adapt_interval = 1; tune.auto_skin = _auto_skin ? 1 : 0;
             chk(gd_set_tuning(_sys, &tune));
         }
         _buffer.resize(3 * _n * _R);
@@ -361,6 +361,7 @@ private:
     std::vector<std::unique_ptr<gd::trajectory_store>> &_stores;
     std::size_t _R;
     gd::simulation_config _config;
+    bool _auto_skin = true;
     std::vector<gd::context> _context;
     double _contact_distance = 0;
     std::vector<std::mt19937_64> _random;
@@ -380,13 +381,15 @@ int main(int argc, char **argv)
 {
     // gd_interphase <trajectory> [device]                      the reference's command line
     // gd_interphase [--device d] <trajectory> <trajectory>...  R prepared files as R replicas of one handle
+    // options: --timing (wall-time split on stderr at the end), --fixed-skin (no list-width selection)
     std::vector<std::string> files;
     int device = 0;
-    bool timing = false;
+    bool timing = false, auto_skin = true;
     auto const t_start = std::chrono::steady_clock::now();
     for (int i = 1; i < argc; i++) {
         std::string const arg = argv[i];
         if (arg == "--timing") timing = true;
+        else if (arg == "--fixed-skin") auto_skin = false;      // keep the library's default list width (no selection sweeps)
         else if (arg == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
         else files.push_back(arg);
     }
@@ -404,7 +407,7 @@ int main(int argc, char **argv)
             for (auto const &f : files) stores.push_back(std::make_unique<gd::trajectory_store>(f));
         }
         {
-            simulation_driver driver{stores, device};
+            simulation_driver driver{stores, device, auto_skin};
             driver.run();
         }
         { TIMED("close_files"); stores.clear(); }
