@@ -11,8 +11,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <ctime>
+#include <future>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -21,6 +23,7 @@
 #include "../../include/gdyn.h"
 #include "gd_config.hpp"
 #include "gd_genome_model.hpp"
+#include "gd_async_io.hpp"
 #include "gd_store.hpp"
 
 namespace {
@@ -45,7 +48,7 @@ public:
     }
     ~simulation_driver() { gd_destroy(_sys); }
 
-    void run() { run_simulation(); }
+    void run() { run_simulation(); _writer.drain(); }
 
 private:
     // simulation_driver.cc:38-57
@@ -92,9 +95,22 @@ private:
             }
             if (logging) print_progress("fine", step);
             if (sampling) {
+                // a snapshot every 100 steps of ~20 us: deflating it (~9 ms) on the stepping thread would be five times the stepping.
+                // Each snapshot is packed on a thread of its own as soon as it is downloaded; the writer thread takes them in order
+                // (gd_async_io.hpp), at most `pending` of them in flight.
                 chk(gd_get_positions_f32(_sys, _buffer.data(), /*quantize=*/1));
-                _store.save_positions(step, _buffer.data(), _n);
-                _store.save_context(step, _context);
+                auto xyz = std::make_shared<std::vector<float>>(_buffer);
+                std::size_t const n = _n;
+                auto packed = std::make_shared<std::future<gd::h5::packed_array>>(std::async(std::launch::async, [xyz, n] {
+                    auto p = gd::h5::plan_packed(n, 3, sizeof(float));
+                    for (std::size_t c = 0; c < p.chunk_count(); c++) gd::h5::pack_chunk(p, c, xyz->data());
+                    return p;
+                }));
+                gd::context const ctx = _context;
+                _writer.submit([this, step, packed, ctx] {
+                    _store.save_positions_packed(step, packed->get());
+                    _store.save_context(step, ctx);
+                });
             }
         };
 
@@ -132,6 +148,7 @@ private:
     gd_system *_sys = nullptr;
     std::size_t _n = 0;
     std::vector<float> _buffer;
+    gd::async_writer _writer{std::max<std::size_t>(1, gd::usable_threads(12))};      // snapshots in flight (packing threads + the queue); destroyed first
 };
 
 }  // namespace

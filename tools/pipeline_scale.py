@@ -60,7 +60,14 @@ t_inter, res = run(os.path.join(HOST, "gd_interphase"), "--timing", *os.environ.
 log = [ln for ln in res.stderr.splitlines() if ln.startswith("[")]
 total_steps = cfg["relaxation_steps"] + steps
 size = sum(os.path.getsize(f) for f in files)
-print(json.dumps({"n_beads": n_beads, "replicas": R, "relaxation_steps": cfg["relaxation_steps"], "interphase_steps": steps,
+fine = None
+if os.environ.get("FINE_STEPS"):      # gd_fine_sampling on the first file, restarted from the last interphase snapshot (a snapshot every 100 steps)
+    env["GD_FINE_STEPS"] = os.environ["FINE_STEPS"]
+    t_fine, _ = run(os.path.join(HOST, "gd_fine_sampling"), files[0], 0, steps)
+    fine = {"steps": int(os.environ["FINE_STEPS"]), "seconds": t_fine}
+    if os.environ.get("FINE_AB"):      # (A/B against another build of the program, same restart)
+        fine["seconds_" + os.path.basename(os.environ["FINE_AB"])] = run(os.environ["FINE_AB"], files[0], 0, steps)[0]
+print(json.dumps({"fine_sampling": fine, "n_beads": n_beads, "replicas": R, "relaxation_steps": cfg["relaxation_steps"], "interphase_steps": steps,
                   "seconds_prepare_spindle_refine_per_file": {k: v / R for k, v in t_prep.items()},
                   "seconds_gd_interphase": t_inter, "bead_steps_per_s_end_to_end": n_beads * R * total_steps / t_inter,
                   "output_MB": size / 1e6, "timing": [ln for ln in log if ln.startswith("[timing]")], "last_log_lines": log[-3:-1]}))
