@@ -707,6 +707,37 @@ def test_equilibrium_statistics_match_oracle(hip, oracle):
     assert np.allclose(ah, ao, rtol=2e-3)                   # the wall ODE integrates the same mean reaction
 
 
+def test_contact_maps_at_scale_accumulate_like_the_oracle(hip, oracle):
+    """gd_contacts_update inside a run at the benchmark's size (8 x 30 000 beads, tiled lists, the reference's contact distance
+    0.4 x bead_scale > the force cutoff): three updates 37 steps apart -- served from the resident list or after one build at the
+    larger radius -- then the dumped rows of two replicas against the oracle's accumulation over the same three structures."""
+    R = 8
+    s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=R)
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    s.begin_phase()
+    s.run(300, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+    so = g.System(oracle, 30000, 2)
+    near = [set(), set()]
+    for k in range(3):
+        s.run(37, info["timestep"], info["temperature"], seed=SEED + 1 + k, flags=flags | g.RUN_DEFER_CALLBACK)
+        dist = 0.4 * s.context(0).bead_scale
+        s.contacts_update(dist)
+        x = s.positions()
+        s.apply_callback()
+        so.set_positions(x[[1, R - 1]])
+        so.contacts_update(dist)
+    assert s.context(0).list_path == 2
+    for q, r in enumerate((1, R - 1)):
+        rh, ro = s.contacts(r), so.contacts(q)
+        assert len(ro) > 200000 and abs(len(rh) - len(ro)) < 40
+        kh = dict(zip(map(tuple, rh[:, :2].tolist()), rh[:, 2].tolist()))
+        ko = dict(zip(map(tuple, ro[:, :2].tolist()), ro[:, 2].tolist()))
+        diff = [pr for pr in set(kh) | set(ko) if kh.get(pr, 0) != ko.get(pr, 0)]
+        assert len(diff) < 40 and all(abs(kh.get(pr, 0) - ko.get(pr, 0)) == 1 for pr in diff)      # (borderline pairs only)
+        key = rh[:, 0].astype(np.int64) << 32 | rh[:, 1].astype(np.int64)
+        assert np.all(np.diff(key) > 0) and rh[:, 2].max() == 3
+
+
 def test_energy_after_a_deferred_run_uses_the_verified_resident_list(hip, oracle):
     """The drivers observe after a GD_RUN_DEFER_CALLBACK run: an accepted chunk has verified the resident list for exactly the
     positions and cutoff gd_compute_energy then sees, so it must not cost a list build -- and the energy must be the one a fresh
