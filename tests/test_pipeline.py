@@ -192,9 +192,12 @@ def test_batched_interphase_takes_files_prepared_with_different_master_seeds(tmp
         _run(spindle, f, env=env)
         _run(sys.executable, os.path.join(HOST, "gd_refine.py"), f)
         files.append(f)
-    _run(interphase, files[0], files[1], env=env)
+    log = _run(interphase, "--timing", "--fixed-skin", files[0], files[1], env=env)
     for f in files[:2]:
         assert _tool("steps", f, "interphase").split() == ["0", "20", "40", "60"]
+    timing = [ln for ln in log.stderr.splitlines() if ln.startswith("[timing]")]      # the wall-time split of the run, stepping and writer threads
+    assert any("gd_run" in ln and "w:pack" in ln and "w:hdf5" in ln and "total" in ln for ln in timing)
+    assert any("packing pool of" in ln for ln in timing) and any("interphase: list path" in ln for ln in timing)
     r = subprocess.run([str(interphase), str(files[0]), str(files[2])], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "share one simulation config" in r.stderr
 
