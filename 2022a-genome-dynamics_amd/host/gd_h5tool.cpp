@@ -13,13 +13,18 @@
 //   gd_h5tool contacts <file> <phase> <step>           prints "i j count" rows
 //   gd_h5tool dataset <file> <path> <out.f64>          any numeric dataset as raw doubles; prints its shape
 //   gd_h5tool strings <file> <path>                    a string dataset (scalar or 1-d), one item per line
+//   gd_h5tool io-selftest                              gd_async_io.hpp: jobs run in submission order, drain() fences, a job's exception reaches the
+//        submitting thread, the pool runs every index once and rethrows
 //   gd_h5tool packed-check <file> <rows>               the same (rows,3) uint32 and float arrays written by the library's filter pipeline and
 //        as hand-packed chunks on a thread pool (gd_h5util.hpp, gd_async_io.hpp); reads both back, compares values, chunking and filters
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hdf5.h>
@@ -190,6 +195,41 @@ int main(int argc, char **argv)
             std::ofstream out(argv[4], std::ios::binary);
             out.write(reinterpret_cast<char const *>(v.data()), (std::streamsize)(count * sizeof(double)));
             return 0;
+        }
+        if (cmd == "io-selftest") {
+            bool ok = true;
+            {   // order and fence
+                std::vector<int> seen;
+                gd::async_writer w(2);
+                for (int k = 0; k < 50; k++) w.submit([&seen, k] { if (k % 7 == 0) std::this_thread::sleep_for(std::chrono::milliseconds(2)); seen.push_back(k); });
+                w.drain();
+                for (int k = 0; k < 50; k++) ok = ok && seen.size() == 50 && seen[(std::size_t)k] == k;
+            }
+            {   // a failing job: the error surfaces at the next submit or drain, later jobs are dropped, the writer stays usable
+                gd::async_writer w(4);
+                int ran = 0;
+                w.submit([] { throw std::runtime_error("job failed"); });
+                bool caught = false;
+                try { for (int k = 0; k < 20; k++) { w.submit([&ran] { ran++; }); std::this_thread::sleep_for(std::chrono::milliseconds(1)); } w.drain(); }
+                catch (std::runtime_error const &e) { caught = std::string(e.what()) == "job failed"; }
+                int after = 0;
+                w.submit([&after] { after = 1; });
+                w.drain();
+                ok = ok && caught && after == 1;
+            }
+            {   // pool: every index exactly once, from several threads; an exception comes back to the caller
+                gd::thread_pool pool(4);
+                std::vector<std::atomic<int>> hits(1000);
+                for (int round = 0; round < 20; round++) pool.parallel_for(hits.size(), [&](std::size_t i) { hits[i]++; });
+                for (auto &h : hits) ok = ok && h == 20;
+                bool caught = false;
+                try { pool.parallel_for(100, [](std::size_t i) { if (i == 37) throw std::runtime_error("task failed"); }); }
+                catch (std::runtime_error const &) { caught = true; }
+                pool.parallel_for(10, [&](std::size_t i) { hits[i]++; });
+                ok = ok && caught && hits[0] == 21;
+            }
+            std::cout << (ok ? "io-selftest ok" : "io-selftest FAILED") << ", " << gd::usable_cpus() << " usable CPUs\n";
+            return ok ? 0 : 1;
         }
         if (cmd == "packed-check" && argc == 4) {
             using namespace gd::h5;

@@ -103,6 +103,13 @@ def _positions(tmp, phase, step):
     return np.fromfile(tmp / "out.f64", dtype="<f8").reshape(-1, 3)
 
 
+def test_async_writer_and_thread_pool_selftest():
+    """gd_async_io.hpp: jobs run in submission order behind a bounded queue, drain() fences, a job's exception reaches the
+    submitting thread and the writer stays usable; the pool runs every index exactly once and rethrows a task's exception."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "h5lib/libhdf5.so", "gd_h5tool"])
+    assert _tool("io-selftest").startswith("io-selftest ok")
+
+
 @pytest.mark.parametrize("rows", [0, 1, 5000, 87381, 87382, 400001])
 def test_hand_packed_chunks_read_back_like_the_library_pipeline(tmp_path, rows):
     """Batched drivers deflate their chunks on a thread pool and hand them to the file as they are (H5Dwrite_chunk): the datasets
