@@ -505,6 +505,7 @@ extern "C" int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     o->rebuild_interval = s->K; o->list_radius = s->rv;
     o->list_path = !s->list_valid && s->rebuilds == 0 ? 0u : (s->list_tiled ? 2u : 1u);
     o->callback_pending = c.pending ? 1u : 0u;
+    o->tile_capacity = (s->list_valid && s->list_tiled) ? s->list_tile_cap : 0u;
     return GD_OK;
 }
 

@@ -318,7 +318,7 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
 // with / without AB mixing (compile-time), PK=0: runtime powers.
 // S16 (tiled lists only): entries are BYTE offsets into the tile (tile capacity < 4096 entries), one decode
 // instruction per entry instead of mask + shift-add
-template <int MODE, bool PERIODIC, bool TILED, int PK, bool S16>
+template <int MODE, bool PERIODIC, bool TILED, int PK, bool S16, bool SPLIT = false>
 #ifndef GD_STEP_WAVES
 #define GD_STEP_WAVES 8      // waves per SIMD the tiled step kernel with byte-offset entries is compiled for: 8 = at most 64 VGPRs.  LDS
                              // admits three blocks per CU (6 waves per SIMD, 80 VGPRs would do), but the 64-register form -- four
@@ -336,6 +336,11 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
 
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
+    if (TILED && SPLIT) {      // a step split by tile size (launch_step_mode): this launch takes the blocks of one LDS class
+                               // (an instantiation of its own: the unsplit kernel carries no trace of it)
+        const unsigned held = p.tiles[(size_t)r * p.nblk + blk].total;
+        if (held <= p.tile_lo || held > p.tile_hi) return;
+    }
     const unsigned tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const size_t rbase = (size_t)r * p.Np;
     const float4 *__restrict__ rpos = p.pos_in + rbase;
@@ -937,8 +942,35 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
     }
-#define L(PER, TIL, PK, S) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK, S>), grid, block, lds, st, p)
     const bool s16 = p.tiled && p.tile_cap < 4096u;      // must match k_fill's choice (gd_launch_build)
+    // The LDS class of a launch is set by the LARGEST tile of any replica, and one tile a few beads over the three-block class
+    // (3 312) costs every block a third of its occupancy (S-genome-62k x 64: a handful of tiles in the nucleus' centre).  While the
+    // list entries stay 16-bit byte offsets (tile_cap < 4 096: the same kernel variant), the step is launched twice instead:
+    // the blocks whose tile fits 3 312 with that much LDS, then the rest; each block returns at once from the launch it is not in.
+    // (Stepping only: force / energy evaluations are rare and run in the larger class.)
+    if (MODE == GD_MODE_STEP && s16 && p.tile_cap > 3312u) {
+        static bool once_split = false;
+        if (!once_split) {
+            once_split = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, false, true, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, false, true, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, false, true, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, true, true, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, true, true, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, true, true, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        }
+        StepParams q = p;
+        for (int half = 0; half < 2; half++) {
+            q.tile_cap = half ? p.tile_cap : 3312u; q.tile_lo = half ? 3312u : 0u; q.tile_hi = half ? 0xffffffffu : 3312u;
+            const size_t lds_q = (size_t)q.tile_cap * sizeof(float4);
+#define LS(PER, PK) hipLaunchKernelGGL((k_step<GD_MODE_STEP, PER, true, PK, true, true>), grid, block, lds_q, st, q)
+            if (p.periodic) { if (p.pk == 1) LS(true, 1); else if (p.pk == 2) LS(true, 2); else LS(true, 0); }
+            else { if (p.pk == 1) LS(false, 1); else if (p.pk == 2) LS(false, 2); else LS(false, 0); }
+#undef LS
+        }
+        return;
+    }
+#define L(PER, TIL, PK, S) hipLaunchKernelGGL((k_step<MODE, PER, TIL, PK, S>), grid, block, lds, st, p)
     if (p.periodic && p.tiled && s16) { if (p.pk == 1) L(true, true, 1, true); else if (p.pk == 2) L(true, true, 2, true); else L(true, true, 0, true); }
     else if (p.periodic && p.tiled) { if (p.pk == 1) L(true, true, 1, false); else if (p.pk == 2) L(true, true, 2, false); else L(true, true, 0, false); }
     else if (p.periodic) { if (p.pk == 1) L(true, false, 1, false); else if (p.pk == 2) L(true, false, 2, false); else L(true, false, 0, false); }

@@ -158,6 +158,8 @@ struct StepParams {
     int packed_ab;                      // 1: pos.w holds (a,b) as two fp16 (exactly representable)
     unsigned cpb;                       // blocks per replica per XCD (XCD-aware block mapping)
     unsigned tile_cap;                  // beads of LDS per block
+    unsigned tile_lo, tile_hi;          // tile_hi != 0: this launch runs only the blocks whose tile holds tile_lo < beads <= tile_hi (the
+                                        // step is then two launches: the tiles that fit the three-block LDS class, and the few larger ones)
     // tiled path: per-THREAD records written by the build (threads of a block are ordered by list length so that the
     // lanes of a wave run the same number of list batches): build position + block-local slot, meta + bead id
     const float4 *rec_x0;

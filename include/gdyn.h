@@ -218,6 +218,7 @@ typedef struct {
     double   list_radius;
     uint32_t list_path;      /* kernel path of the list in use: 0 none yet, 1 generic (global gather), 2 LDS-tiled */
     uint32_t callback_pending;   /* 1: the state updates of callback(step + 1) are pending (GD_RUN_DEFER_CALLBACK) */
+    uint32_t tile_capacity;      /* LDS-tiled lists: beads of LDS per block the list in use was built for (0 on the generic path) */
 } gd_context;
 
 int gd_get_context(gd_system *sys, uint32_t replica, gd_context *out);

@@ -490,7 +490,7 @@ int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     ctx_t *c = &s->ctx[r];
     o->step = c->step; o->time = c->time; o->bead_scale = c->bead_scale; o->bond_scale = c->bond_scale;
     memcpy(o->semiaxes, c->semi, sizeof c->semi); memcpy(o->axial_reaction, c->react, sizeof c->react);
-    o->rebuilds = s->rebuilds; o->callback_pending = (uint32_t)c->pending;
+    o->rebuilds = s->rebuilds; o->callback_pending = (uint32_t)c->pending; o->tile_capacity = 0;
     if (s->vl_start[r]) { o->list_entries = 2ull * s->vl_start[r][s->N]; o->list_radius = s->vl_rv[r]; }
     return GD_OK;
 }

@@ -889,6 +889,31 @@ def test_full_size_noisy_trajectories(hip, oracle, n_beads):
     assert sh.context().step == so.context().step == 5
 
 
+def test_step_split_by_tile_class_matches_oracle(hip, oracle):
+    """When the largest tile of a build lies just above the three-block LDS class (3 312 < capacity < 4 096, the S-genome-62k x 64
+    case) a step is two launches -- the blocks whose tile fits 3 312, then the rest.  Every bead must still be moved exactly once:
+    a list width that lands in that class, five noisy steps of two replicas against the oracle."""
+    chosen = None
+    for skin in (1.1, 1.05, 1.15, 1.0, 1.2):
+        sh, info = wl.genome_interphase(hip, n_beads=62178, n_replicas=2, bead_scale_init=0.8)
+        sh.set_tuning(skin=skin, adapt_interval=0, rebuild_interval=4)
+        sh.begin_phase()
+        sh.energy()                                   # builds the list: the tile class of this width
+        if 3312 < sh.context().tile_capacity < 4096:
+            chosen = skin
+            break
+        sh.close()
+    assert chosen is not None, "no list width in the split class"
+    so, _ = wl.genome_interphase(oracle, n_beads=62178, n_replicas=2, bead_scale_init=0.8)
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    so.begin_phase()
+    for s in (sh, so):
+        s.run(5, info["timestep"], info["temperature"], seed=SEED, flags=flags)
+    c = sh.context()
+    assert 3312 < c.tile_capacity < 4096 and c.list_path == 2 and c.rollbacks == 0
+    assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
+
+
 def test_auto_skin_sweep_keeps_results_and_settles(hip, oracle):
     """gd_tuning.auto_skin: the list width is selected from measured chunk times while the run goes on (candidate widths, each
     for a few verified chunks).  Whatever it selects, the lists are verified: after the sweep the forces on the current positions

@@ -4,7 +4,7 @@ half the bytes of 16-byte-per-lane streaming reads).  usage: traffic_json.py <ta
 import hashlib, json, os, re, sys
 tag = sys.argv[1]; d = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
 # usage: traffic_json.py <tag> [dir [kernel [n_beads replicas [suffix]]]]
-kern = sys.argv[3] if len(sys.argv) > 3 else "k_step<0, false, true, 1, true>"
+kern = sys.argv[3] if len(sys.argv) > 3 else "k_step<0, false, true, 1, true, false>"
 n_beads, replicas = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (30000, 128)
 suffix = sys.argv[6] if len(sys.argv) > 6 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
