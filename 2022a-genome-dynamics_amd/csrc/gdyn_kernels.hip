@@ -947,25 +947,30 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
     // (3 312) costs every block a third of its occupancy (S-genome-62k x 64: a handful of tiles in the nucleus' centre).  While the
     // list entries stay 16-bit byte offsets (tile_cap < 4 096: the same kernel variant), the step is launched twice instead:
     // the blocks whose tile fits 3 312 with that much LDS, then the rest; each block returns at once from the launch it is not in.
+    // The same one class up: tiles beyond 5 072 entries (dense states: one block per CU) next to tiles that fit two blocks per CU.
     // (Stepping only: force / energy evaluations are rare and run in the larger class.)
-    if (MODE == GD_MODE_STEP && s16 && p.tile_cap > 3312u) {
+    const unsigned split_at = !p.tiled ? 0u : (s16 && p.tile_cap > 3312u) ? 3312u : (!s16 && p.tile_cap > 5072u) ? 5072u : 0u;
+    if (MODE == GD_MODE_STEP && split_at) {
         static bool once_split = false;
         if (!once_split) {
             once_split = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, false, true, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, false, true, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, false, true, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, true, true, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, true, true, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, true, true, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+#define AS(PER, PK, S) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, PER, true, PK, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)
+            AS(false, 0, true); AS(false, 1, true); AS(false, 2, true); AS(true, 0, true); AS(true, 1, true); AS(true, 2, true);
+            AS(false, 0, false); AS(false, 1, false); AS(false, 2, false); AS(true, 0, false); AS(true, 1, false); AS(true, 2, false);
+#undef AS
         }
         StepParams q = p;
         for (int half = 0; half < 2; half++) {
-            q.tile_cap = half ? p.tile_cap : 3312u; q.tile_lo = half ? 3312u : 0u; q.tile_hi = half ? 0xffffffffu : 3312u;
+            q.tile_cap = half ? p.tile_cap : split_at; q.tile_lo = half ? split_at : 0u; q.tile_hi = half ? 0xffffffffu : split_at;
             const size_t lds_q = (size_t)q.tile_cap * sizeof(float4);
-#define LS(PER, PK) hipLaunchKernelGGL((k_step<GD_MODE_STEP, PER, true, PK, true, true>), grid, block, lds_q, st, q)
-            if (p.periodic) { if (p.pk == 1) LS(true, 1); else if (p.pk == 2) LS(true, 2); else LS(true, 0); }
-            else { if (p.pk == 1) LS(false, 1); else if (p.pk == 2) LS(false, 2); else LS(false, 0); }
+#define LS(PER, PK, S) hipLaunchKernelGGL((k_step<GD_MODE_STEP, PER, true, PK, S, true>), grid, block, lds_q, st, q)
+            if (s16) {
+                if (p.periodic) { if (p.pk == 1) LS(true, 1, true); else if (p.pk == 2) LS(true, 2, true); else LS(true, 0, true); }
+                else { if (p.pk == 1) LS(false, 1, true); else if (p.pk == 2) LS(false, 2, true); else LS(false, 0, true); }
+            } else {
+                if (p.periodic) { if (p.pk == 1) LS(true, 1, false); else if (p.pk == 2) LS(true, 2, false); else LS(true, 0, false); }
+                else { if (p.pk == 1) LS(false, 1, false); else if (p.pk == 2) LS(false, 2, false); else LS(false, 0, false); }
+            }
 #undef LS
         }
         return;

@@ -914,6 +914,23 @@ def test_step_split_by_tile_class_matches_oracle(hip, oracle):
     assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP
 
 
+def test_step_split_in_a_dense_state_matches_oracle(hip, oracle):
+    """The same split one class up: S-genome-30k compressed to half its size (about 200 list entries per bead) builds tiles beyond
+    5 072 entries -- one block per CU -- next to tiles that fit two; five noisy steps of two replicas against the oracle."""
+    sh, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=2)
+    so, _ = wl.genome_interphase(oracle, n_beads=30000, n_replicas=2)
+    x = sh.positions() * 0.5
+    for s in (sh, so):
+        s.set_positions(x)
+        s.begin_phase()
+    sh.set_tuning(adapt_interval=0, rebuild_interval=3)
+    for s in (sh, so):
+        s.run(5, info["timestep"], info["temperature"], seed=SEED, flags=0)
+    c = sh.context()
+    assert c.tile_capacity > 5072 and c.list_path == 2 and c.list_entries / 30000 > 150
+    assert np.abs(sh.positions() - so.positions()).max() <= 3 * POS_ATOL_20STEP      # (forces ten times the benchmark state's)
+
+
 def test_auto_skin_sweep_keeps_results_and_settles(hip, oracle):
     """gd_tuning.auto_skin: the list width is selected from measured chunk times while the run goes on (candidate widths, each
     for a few verified chunks).  Whatever it selects, the lists are verified: after the sweep the forces on the current positions
