@@ -147,6 +147,16 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
         s.begin_phase()
         if relax:
             s.run(relax, dt, kT, seed=5, flags=0)
+            if tune and tune.get("auto_skin"):
+                # the list-width selection sweeps candidate widths for a few thousand steps: the timed steps start once the width
+                # has stood still (and nothing rolled back) for 1 000 steps, within a bound
+                for _ in range(10):
+                    c0 = s.context()
+                    s.run(1000, dt, kT, seed=5, flags=0)
+                    c1 = s.context()
+                    if c1.list_radius == c0.list_radius and c1.rollbacks == c0.rollbacks:
+                        break
+                    relax += 1000
             s.begin_phase()
         s.run(max(steps // 4, 40), dt, kT, seed=6, flags=flags)
         rb0 = s.context().rollbacks
@@ -171,6 +181,8 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=1, device=dev_index), f3, 4000, 2 * budget_steps)
     run_one("S-genome-62k x 32 replicas (production bead count)",
             lambda: wl.genome_interphase(hip, n_beads=62178, n_replicas=32, device=dev_index), f3, 4000, budget_steps)
+    run_one("S-genome-62k x 64 replicas (production bead count, as many beads per launch as the headline: steps split by tile class)",
+            lambda: wl.genome_interphase(hip, n_beads=62178, n_replicas=64, device=dev_index), f3, 4000, budget_steps)
     run_one("S-genome-30k x 128, bead_scale_init 0.5 (time-varying cutoff, simulation_driver_forcefield.cc:47-49)",
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, bead_scale_init=0.5, device=dev_index), f3, 4000, budget_steps)
     run_one("S-genome-30k x 128, 2nd-bond spring 0 (variant of SURVEY 8d)",
