@@ -24,8 +24,9 @@ LIBGDYN_PATH = os.path.join(_HERE, "csrc", "libgdyn.so")      # the product libr
 GD_BOX_OPEN, GD_BOX_PERIODIC = 0, 1
 POT_HARMONIC, POT_SPRING, POT_SEMISPRING, POT_SOFTCORE = 0, 1, 2, 3
 NOISE_PHILOX, NOISE_ZERO, NOISE_HOST, NOISE_MT19937 = 0, 1, 2, 3
-RUN_UPDATE_SCALES, RUN_WALL_DYNAMICS, RUN_DEFER_CALLBACK = 1, 2, 4
+RUN_UPDATE_SCALES, RUN_WALL_DYNAMICS, RUN_DEFER_CALLBACK, RUN_COMPENSATED, RUN_UNCOMPENSATED = 1, 2, 4, 8, 16
 ALL_REPLICAS = 0xffffffff
+ABI_VERSION = 4            # GD_ABI_VERSION of the include/gdyn.h these ctypes structures mirror
 TERM_PAIR, TERM_BOND, TERM_BEND, TERM_POINT, TERM_WALL, TERM_DYNAMIC, TERM_ALL = 1, 2, 4, 8, 16, 32, 63
 
 _STATUS = {1: "GD_EINVAL", 2: "GD_ENODEVICE", 3: "GD_EHIP", 4: "GD_ENOMEM", 5: "GD_ESTATE", 6: "GD_EUNSUPPORTED"}
@@ -67,7 +68,7 @@ class Context(C.Structure):
                 ("semiaxes", C.c_double * 3), ("axial_reaction", C.c_double * 3),
                 ("list_entries", C.c_uint64), ("rebuilds", C.c_uint64), ("rollbacks", C.c_uint64),
                 ("rebuild_interval", C.c_uint32), ("list_radius", C.c_double), ("list_path", C.c_uint32),
-                ("callback_pending", C.c_uint32), ("tile_capacity", C.c_uint32)]
+                ("callback_pending", C.c_uint32), ("tile_capacity", C.c_uint32), ("compensated", C.c_uint32)]
 
 
 class _RunDesc(C.Structure):
@@ -96,7 +97,7 @@ class InnerSphere(C.Structure):
 
 
 ABI_SYMBOLS = [
-    "gd_last_error", "gd_backend_name", "gd_create", "gd_destroy", "gd_set_positions", "gd_get_positions",
+    "gd_last_error", "gd_backend_name", "gd_abi_version", "gd_create_abi", "gd_destroy", "gd_set_positions", "gd_get_positions",
     "gd_get_positions_f32", "gd_set_bead_params", "gd_set_pair_softcore", "gd_add_bond_range",
     "gd_add_bond_pairs", "gd_set_dynamic_pairs", "gd_add_bending_range", "gd_add_point_source",
     "gd_set_ellipsoid_wall", "gd_set_inner_sphere_wall", "gd_set_pair_softwell", "gd_set_scaling", "gd_get_context", "gd_begin_phase", "gd_set_context",
@@ -127,7 +128,10 @@ class Lib:
         d = self.dll
         d.gd_last_error.restype = C.c_char_p
         d.gd_backend_name.restype = C.c_char_p
-        d.gd_create.argtypes = [C.POINTER(_Desc), C.POINTER(C.c_void_p)]
+        d.gd_abi_version.restype = C.c_int
+        if d.gd_abi_version() != ABI_VERSION:      # the ctypes structures below mirror ONE version of include/gdyn.h
+            raise OSError(f"{path}: ABI version {d.gd_abi_version()}, this binding mirrors version {ABI_VERSION} of include/gdyn.h")
+        d.gd_create_abi.argtypes = [C.c_int, C.POINTER(_Desc), C.POINTER(C.c_void_p)]
         d.gd_destroy.argtypes = [C.c_void_p]
         d.gd_set_positions.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         d.gd_get_positions.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -207,7 +211,7 @@ class System:
         d = _Desc(self.N, self.R, device, GD_BOX_PERIODIC if box is not None else GD_BOX_OPEN,
                   (C.c_double * 3)(*(box if box is not None else (0, 0, 0))))
         self._h = C.c_void_p()
-        lib.check(lib.dll.gd_create(C.byref(d), C.byref(self._h)))
+        lib.check(lib.dll.gd_create_abi(ABI_VERSION, C.byref(d), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -178,6 +178,12 @@ struct gd_system {
     uint64_t verified_serial = 0;  // == state_serial: the last gd_run ended on an accepted chunk, i.e. the resident list was verified for the
                                    // positions and the cutoff an observation now sees (no bead beyond the skin margin): energies need no build
     int ocur = 0;   // which orig[] buffer is current
+    // Compensated positions (small-dt / T = 0 runs, k_step's p.comp): fp32 residuals by bead index, so that the position of a bead is
+    // pos + lo.  gd_set_positions fills them from the fp64 input, a compensated run keeps them, any other run invalidates them.
+    DevBuf<float4> lo, snap_lo;
+    bool lo_valid = false;         // lo describes the current positions (else: taken as zero)
+    bool comp_last = false;        // the last gd_run stepped with the compensated update (diagnostics)
+    double mob_max = 1.0;
     std::vector<hipEvent_t> events;
     ~gd_system()
     {
@@ -188,8 +194,12 @@ struct gd_system {
 
 static int valid_pq(int p, int q) { return (p == 2 || p == 4 || p == 6 || p == 8 || p == 12) && q >= 1 && q <= 4; }
 
-extern "C" int gd_create(const gd_desc *d, gd_system **out)
+extern "C" int gd_abi_version(void) { return GD_ABI_VERSION; }
+
+extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
 {
+    if (abi_version != GD_ABI_VERSION)
+        return fail(GD_EINVAL, "gd_create: the caller was built against gdyn.h ABI version %d, this library implements %d", abi_version, GD_ABI_VERSION);
     if (!d || !out) return fail(GD_EINVAL, "gd_create: NULL argument");
     if (d->n_beads == 0 || d->n_replicas == 0) return fail(GD_EINVAL, "gd_create: n_beads and n_replicas must be > 0");
     if (d->n_beads > GD_ADJ_MASK) return fail(GD_EINVAL, "gd_create: n_beads exceeds %u", GD_ADJ_MASK);
@@ -233,7 +243,9 @@ extern "C" int gd_create(const gd_desc *d, gd_system **out)
          s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->lcount_d.resize(s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
-         s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess;
+         s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess &&
+         s->lo.resize(RN) == hipSuccess;
+    s->lo_valid = ok;      // (positions and residuals all zero)
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
     gd_launch_identity(s->orig[0].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     if (hipStreamSynchronize(s->stream) != hipSuccess) { delete s; return fail(GD_EHIP, "gd_create: identity kernel failed"); }
@@ -276,14 +288,18 @@ extern "C" int gd_set_positions(gd_system *s, const double *xyz)
     if (!s || !xyz) return fail(GD_EINVAL, "gd_set_positions: NULL argument");
     HIPCHK(hipSetDevice(s->device));
     const size_t RN = (size_t)s->R * s->N;
-    std::vector<float4> h(RN);
+    std::vector<float4> h(RN), hl(RN);
     for (size_t i = 0; i < RN; i++) {
         if (!std::isfinite(xyz[3 * i]) || !std::isfinite(xyz[3 * i + 1]) || !std::isfinite(xyz[3 * i + 2]))
             return fail(GD_EINVAL, "gd_set_positions: non-finite coordinate at %zu", 3 * i);
         h[i] = make_float4((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.f);
+        // what the fp32 coordinate drops of the fp64 input: the residual of the compensated update starts from it
+        hl[i] = make_float4((float)(xyz[3 * i] - (double)h[i].x), (float)(xyz[3 * i + 1] - (double)h[i].y), (float)(xyz[3 * i + 2] - (double)h[i].z), 0.f);
     }
     HIPCHK(hipMemcpy2DAsync(s->pos[s->pcur].p, (size_t)s->Np * sizeof(float4), h.data(), (size_t)s->N * sizeof(float4),
                             (size_t)s->N * sizeof(float4), s->R, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->lo.p, hl.data(), RN * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    s->lo_valid = true;
     gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     HIPCHK(hipStreamSynchronize(s->stream));
     s->list_valid = false; s->state_serial++; s->w_packed = false;
@@ -311,6 +327,11 @@ extern "C" int gd_get_positions(gd_system *s, double *xyz)
     GDCHK(fetch_xyz(s, &h, 0));
     const size_t n3 = (size_t)s->R * s->N * 3;
     for (size_t i = 0; i < n3; i++) xyz[i] = h[i];
+    if (s->lo_valid) {      // compensated positions: the fp64 boundary gets pos + lo
+        std::vector<float4> hl(n3 / 3);
+        HIPCHK(hipMemcpy(hl.data(), s->lo.p, hl.size() * sizeof(float4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < hl.size(); i++) { xyz[3 * i] += (double)hl[i].x; xyz[3 * i + 1] += (double)hl[i].y; xyz[3 * i + 2] += (double)hl[i].z; }
+    }
     return GD_OK;
 }
 
@@ -506,6 +527,7 @@ extern "C" int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     o->list_path = !s->list_valid && s->rebuilds == 0 ? 0u : (s->list_tiled ? 2u : 1u);
     o->callback_pending = c.pending ? 1u : 0u;
     o->tile_capacity = (s->list_valid && s->list_tiled) ? s->list_tile_cap : 0u;
+    o->compensated = s->comp_last ? 1u : 0u;
     return GD_OK;
 }
 
@@ -542,7 +564,7 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (t->skin > 0) s->skin = t->skin;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
     s->tuner = gd_system::SkinTuner{};
-    s->tuner.enabled = t->auto_skin != 0 && t->adapt_interval != 0;          // (a fixed cadence: nothing to select for)
+    s->tuner.enabled = (t->auto_skin != 0 || dev_env("GDYN_AUTO_SKIN")) && t->adapt_interval != 0;          // (a fixed cadence: nothing to select for)
     if (t->near_fraction > 0) s->near_frac = t->near_fraction;
     s->a2_ema = 0;
     s->adapt = t->adapt_interval;
@@ -680,6 +702,8 @@ static int finalize_topology(gd_system *s)
     s->WB = WBp; s->has_bend = has_bend; s->has_bonds = !all.empty();
     s->mob_uniform = (float)s->mob[0];
     for (uint32_t i = 1; i < N; i++) if ((float)s->mob[i] != s->mob_uniform) { s->mob_uniform = -1.f; break; }
+    s->mob_max = 0;
+    for (uint32_t i = 0; i < N; i++) s->mob_max = std::max(s->mob_max, s->mob[i]);
     s->topo_dirty = false; s->list_valid = false; s->w_packed = false;
     return GD_OK;
 }
@@ -751,6 +775,7 @@ static void fill_common(gd_system *s, StepParams &p)
     if (dev_env("GDYN_FORCE_FAR")) p.rn = 0.f;      // (timing experiments: the far class in every step)
     if (dev_env("GDYN_FORCE_NEAR")) p.rn = 1e3f;    // (timing experiments with gd_debug_bench only: never the far class -- wrong forces late in an interval)
     p.fout = s->fout.p; p.epart = s->epart.p;
+    p.lo = s->lo.p; p.comp = 0;
 }
 
 // Enqueue one list build (counting sort into slot order + ELL fill) with radius rv.
@@ -1024,6 +1049,23 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
     t.idx = next; t.settle = 1; t.measured = 0; t.acc_ms = 0; t.acc_steps = 0;
 }
 
+// Whether a run steps with the compensated position update (k_step's p.comp).  The increment of a step is mu F dt + sigma xi with
+// sigma = sqrt(2 mu kT dt); once sigma is within a few dozen ulp of an fp32 coordinate -- always at T = 0 -- the rounding of x + dx is no
+// longer small against what a step adds, and summed over a run it is a systematic loss (simulation_fine_sampling: T = 0, dt = 1e-7; an
+// fp32 coordinate of 3 ... 8 has an ulp of 2.4e-7 ... 4.8e-7).  Criterion: sigma < 64 ulp(X), X the coordinate range (largest wall
+// semiaxis / box period; 16 when the model has neither).  GD_RUN_COMPENSATED / GD_RUN_UNCOMPENSATED override it.
+static bool want_compensated(const gd_system *s, const gd_run_desc *run)
+{
+    if (run->flags & GD_RUN_UNCOMPENSATED) return false;
+    if (run->flags & GD_RUN_COMPENSATED) return true;
+    double X = 0;
+    if (s->has_wall) for (auto &c : s->hctx) for (int k = 0; k < 3; k++) X = std::max(X, c.semi[k]);
+    if (s->box_kind == GD_BOX_PERIODIC) for (int k = 0; k < 3; k++) X = std::max(X, s->box[k]);
+    if (!(X > 0)) X = 16.0;
+    const double ulp = std::ldexp(1.0, std::ilogb(X) - 23), sigma = std::sqrt(2.0 * s->mob_max * run->temperature * run->timestep);
+    return sigma < 64.0 * ulp;
+}
+
 extern "C" int gd_apply_callback(gd_system *s)
 {
     if (!s) return fail(GD_EINVAL, "gd_apply_callback: NULL system");
@@ -1059,6 +1101,13 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         HIPCHK(hipMemcpy(s->noise.p, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
     }
 
+    const bool comp = run->steps > 0 && want_compensated(s, run);
+    if (comp) {
+        if (!s->lo_valid) { HIPCHK(hipMemsetAsync(s->lo.p, 0, RN * sizeof(float4), s->stream)); s->lo_valid = true; }
+        HIPCHK(s->snap_lo.resize(RN, false));
+    }
+    if (run->steps > 0) s->comp_last = comp;
+
     if (run->replica_seeds) {
         static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "seed width");
         HIPCHK(s->seeds_d.resize(s->R, false));
@@ -1066,6 +1115,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     }
 
     int64_t done = 0;
+    float last_dmax2 = 0;      // largest bound, over the replicas, of the squared displacement since the build of the positions the last accepted chunk WROTE
     while (done < run->steps) {
         // ---- one verified chunk
         // (while the skin sweep is measuring candidates the chunks are shorter -- four rebuild intervals -- so that a sweep costs
@@ -1075,6 +1125,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                                                                             : std::min<int64_t>(256, std::max<int64_t>(32, 12ll * s->K)));
         // snapshot for rollback: positions in bead order + context
         gd_launch_gather_positions(s->pos[s->pcur].p, s->slot_of.p, s->snap.p, s->N, s->Np, s->R, 0, s->stream);
+        if (comp) HIPCHK(hipMemcpyAsync(s->snap_lo.p, s->lo.p, RN * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
         const std::vector<DevCtx> snap_ctx = s->hctx;
         const bool snap_w_packed = s->w_packed;      // (the snapshot's w is what the positions carried at this point)
         GDCHK(clear_flags(s));
@@ -1119,7 +1170,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 fill_common(s, p);
                 p.dt_d = run->timestep; p.dt = (float)run->timestep; p.kT = (float)run->temperature; p.seed = run->seed;
                 p.seeds = run->replica_seeds ? s->seeds_d.p : nullptr;
-                p.noise_mode = run->noise_mode; p.run_flags = run->flags;
+                p.noise_mode = run->noise_mode; p.run_flags = run->flags; p.comp = comp ? 1 : 0;
                 p.host_noise = host_noise ? s->noise.p + (size_t)(done + k + q) * RN * 3 : nullptr;
                 host_scales(p, k + q);
                 // the interval adaptation needs the displacement at K steps since the build: recorded at the last force
@@ -1153,13 +1204,19 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         std::vector<DevCtx> ctx_new(s->R);
         HIPCHK(hipGetLastError());
         {
-            const size_t nf = f.size() * sizeof(unsigned), nc = s->R * sizeof(DevCtx), nl = s->R * sizeof(unsigned long long);
-            if (!s->h_chunk) HIPCHK(hipHostMalloc((void **)&s->h_chunk, nf + nc + nl, hipHostMallocDefault));
+            const size_t nf = f.size() * sizeof(unsigned), nc = s->R * sizeof(DevCtx), nl = s->R * sizeof(unsigned long long), nd = s->R * sizeof(float);
+            if (!s->h_chunk) HIPCHK(hipHostMalloc((void **)&s->h_chunk, nf + nc + nl + nd, hipHostMallocDefault));
             HIPCHK(hipMemcpyAsync(s->h_chunk, s->flags.p, nf, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(s->h_chunk + nf, s->ctx[s->ccur].p, nc, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc, s->lcount_d.p, nl, hipMemcpyDeviceToHost, s->stream));
+            // the running displacement bound of every replica (tiled path; one word per 128-byte line): it covers the positions the
+            // last step WROTE, which no step has checked yet
+            HIPCHK(hipMemcpy2DAsync(s->h_chunk + nf + nc + nl, sizeof(float), s->dmax.p, GD_DMAX_STRIDE * sizeof(unsigned), sizeof(float), s->R,
+                                    hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
             memcpy(f.data(), s->h_chunk, nf); memcpy(ctx_new.data(), s->h_chunk + nf, nc); memcpy(s->lcount.data(), s->h_chunk + nf + nc, nl);
+            last_dmax2 = 0;
+            for (uint32_t r = 0; r < s->R; r++) { float d2; memcpy(&d2, s->h_chunk + nf + nc + nl + r * sizeof(float), 4); last_dmax2 = std::max(last_dmax2, d2); }
         }
         bool violated = false; float maxd2 = 0;
         for (uint32_t r = 0; r < s->R; r++) {
@@ -1173,6 +1230,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             HIPCHK(hipMemcpy2DAsync(s->pos[s->pcur].p, (size_t)s->Np * sizeof(float4), s->snap.p, (size_t)s->N * sizeof(float4),
                                     (size_t)s->N * sizeof(float4), s->R, hipMemcpyDeviceToDevice, s->stream));
             gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
+            if (comp) HIPCHK(hipMemcpyAsync(s->lo.p, s->snap_lo.p, RN * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
             s->hctx = snap_ctx; s->ctx_dirty = true; s->w_packed = snap_w_packed;
             GDCHK(upload_ctx(s));
             s->list_valid = false;
@@ -1228,12 +1286,19 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         if (with_list) tune_skin(s, ms, chunk, full_interval, false);
         done += chunk;
     }
+    if (run->steps > 0 && !comp) s->lo_valid = false;      // the positions moved without their residuals
     // The last chunk was accepted: every bead is within the margin the list in use was built for, at the cutoff of the last step.
     // That is still the cutoff an observation sees when the scales did not move behind that step (callback deferred, or no scale
     // updates in this run) -- the resident list then serves gd_compute_energy as it is.
     // (Not with the droplet term: its kernel moves beads behind k_step's check.)
-    if (run->steps > 0 && with_list && s->list_valid && !s->sw_n && (!(run->flags & GD_RUN_UPDATE_SCALES) || (run->flags & GD_RUN_DEFER_CALLBACK)))
-        s->verified_serial = s->state_serial;
+    // The checks of a step cover the positions it READ; the positions the last step wrote are covered by the running bound of the
+    // tiled path (dmax: triangle bound of the written positions, read back with the chunk): the list serves an observation only if that
+    // bound is inside the margin too.  The generic path keeps no such bound: its observations build a list.
+    if (run->steps > 0 && with_list && s->list_valid && !s->sw_n && (!(run->flags & GD_RUN_UPDATE_SCALES) || (run->flags & GD_RUN_DEFER_CALLBACK))) {
+        const double cut_obs = pair_cutoff(s) * (s->pair.scale_by_bead_scale ? bead_scale_bound(s, nullptr, 0) : 1.0);
+        const double lim = 0.5 * ((double)s->rv - cut_obs);
+        if (s->list_tiled && lim > 0 && (double)last_dmax2 <= lim * lim) s->verified_serial = s->state_serial;
+    }
     return GD_OK;
 }
 

@@ -846,8 +846,24 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             const float mu_dt = mu * p.dt;
             const float sg = s_ctx.sg_uniform >= 0.f ? s_ctx.sg_uniform : sqrtf(2.0f * p.kT * mu_dt);
             const float ex = mu_dt * F.x + sg * z.x, ey = mu_dt * F.y + sg * z.y, ez = mu_dt * F.z + sg * z.z;
-            if (TILED) *(float4 *)((char *)(p.pos_out + rbase + (size_t)blk * GD_BLOCK) + local * 16u) = make_float4(xi.x + ex, xi.y + ey, xi.z + ez, xi4.w);
-            else p.pos_out[g] = make_float4(xi.x + ex, xi.y + ey, xi.z + ez, xi4.w);
+            float nx = xi.x + ex, ny = xi.y + ey, nz = xi.z + ez;
+            if (p.comp) {
+                // Compensated update (uniform branch; gd_run selects it when the increment of a step is within a few ulp of an
+                // fp32 coordinate: the reference's deterministic fine-sampling run, T = 0 and dt = 1e-7,
+                // simulation_fine_sampling/simulation_driver.cc:30-34, moves a bead by 1e-7 ... 2e-6 per step at |x| of 3 ... 8,
+                // i.e. by 0.1 ... 4 ulp).  The bead's true position is x + lo; the increment is added to the residual first and
+                // the pair is re-normalised by a two-sum (Knuth; exact in round-to-nearest whatever the magnitudes), so that no
+                // part of mu F dt is lost.  Forces are evaluated on x alone: |lo| <= ulp(x) / 2, the rounding every fp32
+                // position carries anyway.  The residual lives by BEAD index, outside the cell sort.
+                float4 *lp = p.lo + ((size_t)r * p.N + oid);
+                const float4 l = *lp;
+                const float tx = l.x + ex, ty = l.y + ey, tz = l.z + ez;
+                nx = xi.x + tx; ny = xi.y + ty; nz = xi.z + tz;
+                const float bx = nx - xi.x, by = ny - xi.y, bz = nz - xi.z;
+                *lp = make_float4((xi.x - (nx - bx)) + (tx - bx), (xi.y - (ny - by)) + (ty - by), (xi.z - (nz - bz)) + (tz - bz), 0.f);
+            }
+            if (TILED) *(float4 *)((char *)(p.pos_out + rbase + (size_t)blk * GD_BLOCK) + local * 16u) = make_float4(nx, ny, nz, xi4.w);
+            else p.pos_out[g] = make_float4(nx, ny, nz, xi4.w);
             // displacement of the NEW position since the build, bounded by the triangle inequality (the build position
             // need not stay in registers): |x + dx - x0| <= |x - x0| + |dx|
             // ((d + e)^2 = d^2 + e^2 + 2 sqrt(d^2 e^2): one square root)
@@ -1993,6 +2009,8 @@ __global__ void k_gather_xyz(const float4 *pos, const unsigned *slot_of, float *
     const unsigned r = blockIdx.y, o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= N) return;
     float4 x = pos[(size_t)r * Np + slot_of[(size_t)r * N + o]];
+    // (simulation_store.cc:403-407 rounds float(val): with compensated positions val = pos + lo and float(pos + lo) == pos, the pair
+    // being normalised -- the residual never enters a snapshot)
     if (quantize) {
         x.x = rintf(x.x * 65536.0f) * (1.0f / 65536.0f);
         x.y = rintf(x.y * 65536.0f) * (1.0f / 65536.0f);

@@ -194,6 +194,10 @@ struct StepParams {
     float rn;                           // near-class radius of the tiled list in use
     unsigned *dmax;                     // [R] largest squared displacement since the build, float bits (monotone between builds)
     int record_disp;
+    // compensated position update (small-dt / T = 0 runs: mu F dt below the ulp of an fp32 coordinate): the true position of a bead is
+    // pos + lo with lo the fp32 residual the rounded sums left behind, [R][N] by BEAD index (it does not take part in the cell sort)
+    float4 *lo;
+    int comp;                           // 1: x += e as a two-sum over (pos, lo)
     // force / energy modes
     unsigned term_mask;
     float4 *fout;                       // [R][N] by bead index

@@ -9,8 +9,11 @@
 // forces/glue_forcefield.cpp); loop extrusion and glue kinetics stay on the host on std::mt19937_64
 // (gd_1kb_kinetics.hpp), the glue candidate search uses the device cell list (gd_search_pairs).
 //
-// GD_1KB_TRACE=<dir> (test support): writes <dir>/init.f64 (initial positions), and <dir>/trace.txt with the
-// integrator seed and every loop / glue list uploaded, so a run can be replayed call by call.
+// Options beyond the reference's: -d <device>; --trace <dir> (test support): writes <dir>/init.f64 (initial positions) and
+// <dir>/trace.txt with the integrator seed and every loop / glue list uploaded, so a run can be replayed call by call;
+// --fixed-skin: keep the library's default list width instead of letting it select one from measured chunk times (the
+// selection changes cost only, but also the cell decomposition and with it the fp32 summation order of a trajectory).
+// The program reads no environment variable.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -85,7 +88,7 @@ gd::loop_extruder make_loop_extruder(simulation_config const &config, std::vecto
 
 class simulation {
 public:
-    simulation(simulation_config const &config, int device)
+    simulation(simulation_config const &config, int device, std::string const &trace_dir = "", bool auto_skin = true)
         : _config(config), _random(make_random(config.sampling.random_seed)), _store(config.sampling.output_filename),
           _chains(make_chain_assignments(_config)), _loops(make_loop_extruder(_config, _chains)),
           _glues(_config.glue.max_glues, _config.glue.glue_distance, _config.glue.glue_binding_rate, _config.glue.glue_unbinding_rate,
@@ -93,7 +96,8 @@ public:
     {
         for (auto const &c : _chains) _n += c.config->length;
         if (_n == 0) throw std::runtime_error("no monomers: the configuration defines no chains");
-        if (char const *dir = std::getenv("GD_1KB_TRACE")) { _trace_dir = dir; _trace.open(_trace_dir + "/trace.txt"); }
+        _auto_skin = auto_skin;
+        if (!trace_dir.empty()) { _trace_dir = trace_dir; _trace.open(_trace_dir + "/trace.txt"); }
         setup_system(device);
         std::vector<int> ranges;
         for (auto const &c : _chains) { ranges.push_back(int(c.start)); ranges.push_back(int(c.end)); }
@@ -119,7 +123,7 @@ private:
         chk(gd_create(&desc, &_sys));
         {   // the list width for this model's density and cutoff: selected by the library from measured chunk times
             gd_tuning tune{};
-            tune.adapt_interval = 1; tune.auto_skin = 1;
+            tune.adapt_interval = 1; tune.auto_skin = _auto_skin ? 1 : 0;
             chk(gd_set_tuning(_sys, &tune));
         }
         std::vector<double> mobility(_n, ch.monomer_mobility), bending(_n, ch.bending_energy);
@@ -297,6 +301,7 @@ private:
     std::vector<double> _xyz;
     std::string _trace_dir;
     std::ofstream _trace;
+    bool _auto_skin = true;
 };
 
 void show_usage()
@@ -309,6 +314,8 @@ void show_usage()
                  "  -o <output>  override output HDF5 filename (config 'output_filename' key)\n"
                  "  -s <seed>    override random seed (config 'random_seed' key)\n"
                  "  -d <device>  GPU index (default 0)\n"
+                 "  --fixed-skin keep the default neighbour-list width (no selection from measured step times)\n"
+                 "  --trace <dir> write the initial positions and every uploaded loop / glue list to <dir> (replay support)\n"
                  "  -h           print this usage message and exit\n\n";
 }
 
@@ -329,6 +336,8 @@ int main(int argc, char **argv)
         std::optional<std::uint64_t> seed;
         std::vector<std::string> positional;
         int device = 0;
+        std::string trace_dir;
+        bool auto_skin = true;
         for (int i = 1; i < argc; i++) {
             std::string const arg = argv[i];
             auto value = [&]() -> std::string { if (i + 1 >= argc) throw std::runtime_error{"bad option"}; return argv[++i]; };
@@ -337,6 +346,8 @@ int main(int argc, char **argv)
             else if (arg == "-o") output_filename = value();
             else if (arg == "-s") seed = std::stoull(value());
             else if (arg == "-d") device = std::stoi(value());
+            else if (arg == "--trace") trace_dir = value();
+            else if (arg == "--fixed-skin") auto_skin = false;
             else if (arg.size() > 1 && arg[0] == '-') throw std::runtime_error{"bad option"};
             else positional.push_back(arg);
         }
@@ -360,7 +371,7 @@ int main(int argc, char **argv)
         }
         if (output_filename) config.sampling.output_filename = *output_filename;
         if (seed) config.sampling.random_seed = *seed;
-        simulation{config, device}.run();
+        simulation{config, device, trace_dir, auto_skin}.run();
         return 0;
     } catch (std::exception const &err) {
         std::cerr << "error: " << err.what() << '\n';

@@ -33,7 +33,7 @@ using gd::chk;
 class simulation_driver {
 public:
     // restart_step is 700000 in the reference (simulation_driver.cc:45); tests restart from shorter trajectories
-    simulation_driver(gd::trajectory_store &store, int device, long restart_step)
+    simulation_driver(gd::trajectory_store &store, int device, long restart_step, long steps_override = 0)
         : _store(store), _config(gd::parse_simulation_config(store.load_config_text())),
           _random(_config.interphase_seed ^ std::uint64_t(700000))
     {
@@ -43,7 +43,7 @@ public:
         _config.interphase_sampling_interval = 100;
         _config.interphase_steps = 1000 * 100;
         _config.interphase_timestep = 1e-5 / 100;
-        if (char const *s = std::getenv("GD_FINE_STEPS")) _config.interphase_steps = std::stol(s);   // shorter runs for tests
+        if (steps_override > 0) _config.interphase_steps = steps_override;      // --steps: shorter runs (tests, timing)
         setup_context(restart_step);
     }
     ~simulation_driver() { gd_destroy(_sys); }
@@ -155,13 +155,21 @@ private:
 
 int main(int argc, char **argv)
 {
-    if (argc < 2 || argc > 4) {
-        std::cerr << "usage: gd_fine_sampling <trajectory> [device [restart_step]]\n";
+    // (the reference program takes the trajectory only; --steps <n> shortens the hard-wired 100 000 steps.  No environment variable is read.)
+    long steps_override = 0;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; i++) {
+        std::string const arg = argv[i];
+        if (arg == "--steps" && i + 1 < argc) steps_override = std::stol(argv[++i]);
+        else pos.push_back(arg);
+    }
+    if (pos.size() < 1 || pos.size() > 3) {
+        std::cerr << "usage: gd_fine_sampling [--steps <n>] <trajectory> [device [restart_step]]\n";
         return 1;
     }
     try {
-        gd::trajectory_store store{argv[1]};
-        simulation_driver driver{store, argc >= 3 ? std::stoi(argv[2]) : 0, argc == 4 ? std::stol(argv[3]) : 700000};
+        gd::trajectory_store store{pos[0]};
+        simulation_driver driver{store, pos.size() >= 2 ? std::stoi(pos[1]) : 0, pos.size() == 3 ? std::stol(pos[2]) : 700000, steps_override};
         driver.run();
     } catch (std::exception const &e) {
         std::cerr << "error: " << e.what() << '\n';

@@ -104,6 +104,30 @@ def cpu_baseline(g, wl, x0, n_beads, budget_s=12.0):
     return base, farm
 
 
+FORCE_RTOL = 5e-5      # tests/util.py: |dF| <= FORCE_RTOL * max|F| (fp32 device vs fp64 oracle)
+
+
+def check_against_oracle(g, wl, sys_, n_beads, replica):
+    """The state the timed steps left behind, checked: forces of one replica of the benchmark handle (same launch shape as the timed
+    steps: all R replicas, tiled lists, the adapted interval) against the fp64 oracle on the same positions and context.
+    Part of the cpu_baseline leg (the oracle is the checker, never the thing measured)."""
+    x = sys_.positions()[replica]
+    c = sys_.context(replica)
+    Fh = sys_.forces()[replica]
+    orc = g.Lib(os.path.join(ROOT, "oracle", "liboracle.so"))
+    so, _ = wl.genome_interphase(orc, n_beads=n_beads, n_replicas=1)
+    so.set_positions(x[None])
+    so.begin_phase()
+    so.set_context(0, c.step, c.bead_scale, c.bond_scale, tuple(c.semiaxes))
+    Fo = so.forces()[0]
+    so.close()
+    scale = float(np.abs(Fo).max())
+    err = float(np.abs(Fh - Fo).max() / scale)
+    return {"replica": replica, "max_rel_force_err": err, "tolerance": FORCE_RTOL, "max_abs_force": scale,
+            "what": "forces of one replica of the timed handle after the timed steps vs oracle/liboracle.so (fp64), |dF|max / |F|max",
+            "list_path": {0: "none", 1: "generic", 2: "tiled"}[sys_.context(0).list_path], "ok": err <= FORCE_RTOL}
+
+
 def _kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
@@ -235,6 +259,7 @@ def main():
             return 0
         return subprocess.run(cmd).returncode
 
+    status = 0
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -368,6 +393,7 @@ def main():
                          "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},
         }
         if not a.no_cpu_baseline and world == 1:
+            out["checked"] = check_against_oracle(g, wl, sys_, N, R // 2)
             out["cpu_baseline"], farm_cpu = cpu_baseline(g, wl, sys_.positions()[0], N)
             out["config"]["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
             if farm_cpu is not None:
@@ -376,9 +402,13 @@ def main():
             sys_.close()
             out["config"]["other_workloads"] = other_workloads(g, wl, hip, dev_index)
         print(json.dumps(out), flush=True)
+        if "checked" in out and not out["checked"]["ok"]:
+            sys.stderr.write(f"bench.py: the timed state fails the oracle check: {out['checked']}\n")
+            status = 3
     sys_.close()
     if grouped:
         dist.destroy_process_group()
+    return status
 
 
 if __name__ == "__main__":

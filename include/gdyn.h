@@ -59,7 +59,14 @@ typedef struct {
     double   box[3];       /* x/y/z period when periodic */
 } gd_desc;
 
-int gd_create(const gd_desc *desc, gd_system **out);
+/* Version of this header's struct layouts (gd_desc, gd_context, gd_run_desc, gd_tuning, gd_timing ...); bumped whenever one
+ * of them changes.  A caller compiled against another version would have the library read or write past its structs, so
+ * handle creation carries the caller's version and fails with GD_EINVAL on a mismatch: gd_create() is a macro over
+ * gd_create_abi().  Bindings that do not go through this header (ctypes) pass their own constant. */
+#define GD_ABI_VERSION 4
+int gd_abi_version(void);
+int gd_create_abi(int abi_version, const gd_desc *desc, gd_system **out);
+#define gd_create(desc, out) gd_create_abi(GD_ABI_VERSION, (desc), (out))
 int gd_destroy(gd_system *sys);
 
 /* md::system::view_positions() (simultion_driver_relaxation.cc:12-15). (R,N,3) fp64. */
@@ -219,6 +226,7 @@ typedef struct {
     uint32_t list_path;      /* kernel path of the list in use: 0 none yet, 1 generic (global gather), 2 LDS-tiled */
     uint32_t callback_pending;   /* 1: the state updates of callback(step + 1) are pending (GD_RUN_DEFER_CALLBACK) */
     uint32_t tile_capacity;      /* LDS-tiled lists: beads of LDS per block the list in use was built for (0 on the generic path) */
+    uint32_t compensated;        /* 1: the last gd_run stepped with the compensated position update (gd_run, below) */
 } gd_context;
 
 int gd_get_context(gd_system *sys, uint32_t replica, gd_context *out);
@@ -235,6 +243,8 @@ enum { GD_NOISE_PHILOX = 0, GD_NOISE_ZERO = 1, GD_NOISE_HOST = 2 };
 enum {
     GD_RUN_UPDATE_SCALES = 1,   /* callback runs update_bead_scale()   (simulation_driver_interphase.cc:42) */
     GD_RUN_WALL_DYNAMICS = 2,   /* callback runs update_wall_semiaxes() (simulation_driver_interphase.cc:43) */
+    GD_RUN_COMPENSATED = 8,     /* force the compensated position update (below) */
+    GD_RUN_UNCOMPENSATED = 16,  /* never use it */
     GD_RUN_DEFER_CALLBACK = 4   /* the state updates of the LAST step's callback are left pending when gd_run returns: positions are
                                    those of step k, the context is the one callback(k-1) left -- what the reference's callback(k)
                                    sees when it computes mean_energy, prints and saves (simulation_driver_interphase.cc:20-22,
@@ -247,7 +257,17 @@ enum {
  * (simulation_driver_interphase.cc:48-55): for k=1..steps
  *     x_i += mu_i F_i dt + sqrt(2 mu_i kT dt) xi_i ;  callback(k)
  * The callback's per-step state updates run on the device (flags); everything else a
- * callback does (logging, sampling) is done by the caller between gd_run() chunks. */
+ * callback does (logging, sampling) is done by the caller between gd_run() chunks.
+ *
+ * Compensated positions.  The reference integrates in fp64; the device keeps fp32 coordinates.  When the increment of a
+ * step comes within a few dozen ulp of a coordinate -- the deterministic fine-sampling run, T = 0 and dt = 1e-7
+ * (simulation_fine_sampling/simulation_driver.cc:30-34) -- the run keeps an fp32 residual per coordinate and adds
+ * increments by a two-sum, so that a bead's position is pos + residual (about 48 significant bits) and no part of
+ * mu F dt is lost; gd_get_positions returns the sum, gd_get_positions_f32 its fp32 part (float(pos + residual), which is what
+ * simulation_store.cc:403-407 quantises).  Selected by gd_run when
+ * sqrt(2 mu_max kT dt) < 64 ulp(largest wall semiaxis / box period; 16 without either), i.e. always at T = 0;
+ * GD_RUN_COMPENSATED / GD_RUN_UNCOMPENSATED override.  gd_set_positions seeds the residuals with what fp32 drops of the
+ * fp64 input; a run without compensation discards them. */
 typedef struct {
     double   temperature;
     double   timestep;

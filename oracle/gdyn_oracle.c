@@ -241,8 +241,12 @@ static double mt64_normal(mt64_t *g)
 
 /* ------------------------------------------------------------------- system */
 
-int gd_create(const gd_desc *d, gd_system **out)
+int gd_abi_version(void) { return GD_ABI_VERSION; }
+
+int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
 {
+    if (abi_version != GD_ABI_VERSION)
+        return fail(GD_EINVAL, "gd_create: the caller was built against gdyn.h ABI version %d, this library implements %d", abi_version, GD_ABI_VERSION);
     if (!d || !out) return fail(GD_EINVAL, "gd_create: NULL argument");
     if (d->n_beads == 0 || d->n_replicas == 0) return fail(GD_EINVAL, "gd_create: n_beads and n_replicas must be > 0");
     if (d->box_kind != GD_BOX_OPEN && d->box_kind != GD_BOX_PERIODIC) return fail(GD_EINVAL, "gd_create: bad box_kind");

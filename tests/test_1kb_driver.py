@@ -1,5 +1,5 @@
 """The stage-3 driver `gd_1kb` above the C-ABI: configuration parsing, output datasets, log
-lines, and a call-by-call replay -- the driver records (GD_1KB_TRACE) its initial positions, the integrator seed and
+lines, and a call-by-call replay -- the driver records (--trace <dir>) its initial positions, the integrator seed and
 every loop / glue list it uploads; the same ABI calls issued from Python must reproduce every saved frame.  The
 kinetics that produce those lists are pinned separately against the reference's own code (test_1kb_kinetics.py)."""
 import json
@@ -94,8 +94,7 @@ def _check(tmp, lib, driver, atol, env=None):
     cfg = _config(tmp)
     (tmp / "config.json").write_text(json.dumps(cfg, indent=1))
     (tmp / "trace").mkdir()
-    r = subprocess.run([str(driver), str(tmp / "config.json")], capture_output=True, text=True,
-                       env=dict(env or os.environ, GD_1KB_TRACE=str(tmp / "trace")))
+    r = subprocess.run([str(driver), "--trace", str(tmp / "trace"), str(tmp / "config.json")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     logs = [ln.split("\t") for ln in r.stderr.splitlines()]
     assert [int(f[0]) for f in logs] == list(range(0, STEPS + 1, 10))

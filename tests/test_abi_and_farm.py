@@ -25,6 +25,20 @@ def test_header_symbols_match_binding():
     assert declared == set(g.ABI_SYMBOLS), declared ^ set(g.ABI_SYMBOLS)
 
 
+def test_abi_version_is_checked_at_handle_creation(oracle):
+    """A caller built against another version of include/gdyn.h (struct layouts) is refused at gd_create: the macro passes the
+    header's GD_ABI_VERSION, the ctypes binding its own constant."""
+    hdr = open(os.path.join(ROOT, "include", "gdyn.h")).read()
+    assert int(re.search(r"#define GD_ABI_VERSION (\d+)", hdr).group(1)) == g.ABI_VERSION
+    import ctypes as C
+    for lib in (oracle, _built()):
+        assert lib.dll.gd_abi_version() == g.ABI_VERSION
+        h = C.c_void_p()
+        d = g._Desc(10, 1, 0, 0, (C.c_double * 3)(0, 0, 0))
+        rc = lib.dll.gd_create_abi(g.ABI_VERSION - 1, C.byref(d), C.byref(h))
+        assert rc == 1 and b"ABI version" in lib.dll.gd_last_error()        # GD_EINVAL
+
+
 def test_libgdyn_loads_and_exports_abi():
     lib = _built()                                   # Lib() raises on any missing symbol
     assert lib.backend == "hip"

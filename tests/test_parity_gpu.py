@@ -983,3 +983,110 @@ def test_mixed_bond_sets_beyond_the_premixed_table(hip, oracle, path):
     assert np.abs(Fh - Fo).max() <= FORCE_RTOL * scale and np.abs(Fbh - Fbo).max() <= FORCE_RTOL * scale
     assert abs(Ebh - Ebo) <= 3 * ENERGY_RTOL * abs(Ebo)
     assert np.abs(xh - xo).max() <= POS_ATOL_20STEP
+
+
+# ---------------------------------------------------------------- the benchmark's launch shape
+
+def test_benchmark_launch_shape_matches_oracle(hip, oracle):
+    """128 x 30 000 beads in one handle -- the shape bench.py times: 7 552 blocks, whole replicas per XCD (block_map), tiled lists,
+    the interval adapted to ~14, 1.4 GB of state.  Forces of replicas 0, 63 and 127 and a 14-step noisy run (one rebuild interval,
+    the far list class joining at its end) against the fp64 oracle, each replica on the stream a solo run with its seed draws."""
+    R, picks = 128, (0, 63, 127)
+    sh, info, flags = _adapted_state(hip, R, steps=600)
+    c0 = sh.context()
+    assert c0.list_path == 2 and 8 <= c0.rebuild_interval <= 24, (c0.list_path, c0.rebuild_interval)
+    x0 = sh.positions()
+    ctx = {r: sh.context(r) for r in picks}
+    Fh = sh.forces()
+    ors = {}
+    for r in picks:
+        so, _ = wl.genome_interphase(oracle, n_beads=30000, n_replicas=1)
+        so.set_positions(x0[r][None])
+        so.set_context(0, ctx[r].step, ctx[r].bead_scale, ctx[r].bond_scale, tuple(ctx[r].semiaxes))
+        Fo = so.forces()[0]
+        assert np.abs(Fh[r] - Fo).max() <= FORCE_RTOL * np.abs(Fo).max(), r
+        ors[r] = so
+    del Fh
+    seeds = SEED + 1000 + np.arange(R, dtype=np.uint64)
+    sh.run(14, info["timestep"], info["temperature"], seed=0, flags=flags, replica_seeds=seeds)
+    c1 = sh.context()
+    assert c1.list_path == 2 and c1.rollbacks == c0.rollbacks
+    xh = sh.positions()
+    for r in picks:
+        so = ors[r]
+        so.run(14, info["timestep"], info["temperature"], seed=int(seeds[r]), flags=flags)
+        assert np.abs(xh[r] - so.positions()[0]).max() <= POS_ATOL_20STEP, r
+        assert sh.context(r).step == so.context(0).step
+        assert np.allclose(np.array(sh.context(r).semiaxes), np.array(so.context(0).semiaxes), rtol=0, atol=1e-8), r
+        so.close()
+
+
+# ---------------------------------------------------------------- small-dt runs: compensated positions
+
+@pytest.mark.parametrize("n_beads", [30000, 62178])
+def test_fine_timestep_displacement_field_matches_oracle(hip, oracle, n_beads):
+    """The reference's deterministic configuration (simulation_fine_sampling/simulation_driver.cc:30-34: T = 0, dt = 1e-5 / 100,
+    fp64) moves a bead by mu F dt ~ 1e-7 ... 2e-6 per step at |x| up to 6.3 / 8.0 -- 0.1 ... 4 ulp of an fp32 coordinate -- and what it
+    outputs is exactly those small displacements.  300 steps from a relaxed state, device vs oracle, on the DISPLACEMENT x(300) - x(0):
+      * max error <= 1e-3 of the median displacement (measured 6e-5), median error <= 1e-5 of it (measured 1e-7);
+      * no coordinate that moves in the oracle stands still on the device, none moves the other way;
+      * gd_run selects the compensated update by itself at T = 0 (gd_context.compensated);
+      * the plain fp32 update (GD_RUN_UNCOMPENSATED) on the same state misses the first bound by more than 20 x (measured 250 x: 3 % median
+        error, 5 % of the coordinates stuck) -- i.e. the bounds can tell the two apart."""
+    s, info = wl.genome_interphase(hip, n_beads=n_beads)
+    s.begin_phase()
+    s.run(3000, info["timestep"], info["temperature"], seed=SEED + 3, flags=0)       # relax the random-walk start: |F| ~ 9 per component
+    assert s.context().compensated == 0                   # sigma = 4.5e-3 per step: plain update
+    x0 = s.positions()
+    s.close()
+    so, _ = wl.genome_interphase(oracle, n_beads=n_beads)
+    so.set_positions(x0)
+    so.begin_phase()
+    so.run(300, 1e-7, 0.0, seed=1, flags=g.RUN_WALL_DYNAMICS)
+    do = so.positions()[0] - x0[0]
+    med = np.median(np.abs(do))
+    assert 1e-4 < med < 1e-3, med
+    moving = np.abs(do) > 1e-6
+    errs = {}
+    for tag, fl in (("auto", 0), ("plain", g.RUN_UNCOMPENSATED)):
+        sh, _ = wl.genome_interphase(hip, n_beads=n_beads)
+        sh.set_positions(x0)
+        sh.begin_phase()
+        sh.run(300, 1e-7, 0.0, seed=1, flags=g.RUN_WALL_DYNAMICS | fl)
+        assert sh.context().compensated == (1 if tag == "auto" else 0) and sh.context().list_path == 2
+        dh = sh.positions()[0] - x0[0]
+        errs[tag] = np.abs(dh - do)
+        if tag == "auto":
+            assert errs[tag].max() <= 1e-3 * med, (errs[tag].max(), med)
+            assert np.median(errs[tag]) <= 1e-5 * med
+            assert np.all(dh[moving] != 0) and np.all(np.sign(dh[moving]) == np.sign(do[moving]))
+            assert abs(sh.context().semiaxes[0] - so.context().semiaxes[0]) <= 1e-10
+        sh.close()
+    assert errs["plain"].max() > 20 * 1e-3 * med and np.median(errs["plain"]) > 1e-3 * med
+
+
+def test_fp64_positions_survive_the_boundary_and_compensated_runs_on_both_paths(hip, oracle):
+    """gd_set_positions keeps what fp32 drops of the fp64 input as the residual of the compensated update: gd_get_positions returns
+    the input to ~1e-14, a noisy (uncompensated) run discards the residuals (positions are fp32 values again), and a T = 0 run
+    at dt = 1e-7 matches the oracle on both kernel paths from an fp64 start the oracle sees identically."""
+    _, _, _, _, flags = CASES["genome"]
+    rng = np.random.default_rng(5)
+    for path in ("generic", "tiled"):
+        sh, dt, kT, _ = build(hip, "genome")
+        so, *_ = build(oracle, "genome")
+        sh.set_tuning(kernel_path=PATHS[path])
+        x = so.positions() + 1e-9 * rng.standard_normal(so.positions().shape)      # not representable in fp32
+        for s in (sh, so):
+            s.set_positions(x)
+            s.begin_phase()
+        assert np.abs(sh.positions() - x).max() <= 1e-13
+        for s in (sh, so):
+            s.run(200, 1e-7, 0.0, seed=3, flags=flags)
+        _assert_path(sh, path)
+        assert sh.context().compensated == 1
+        dh, do = sh.positions() - x, so.positions() - x
+        assert np.abs(dh - do).max() <= 2e-3 * np.median(np.abs(do)), (path, np.abs(dh - do).max(), np.median(np.abs(do)))
+        sh.run(3, dt, kT, seed=4, flags=flags)
+        assert sh.context().compensated == 0
+        xs = sh.positions()
+        assert np.array_equal(xs, xs.astype(np.float32).astype(np.float64))

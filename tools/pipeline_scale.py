@@ -62,11 +62,10 @@ total_steps = cfg["relaxation_steps"] + steps
 size = sum(os.path.getsize(f) for f in files)
 fine = None
 if os.environ.get("FINE_STEPS"):      # gd_fine_sampling on the first file, restarted from the last interphase snapshot (a snapshot every 100 steps)
-    env["GD_FINE_STEPS"] = os.environ["FINE_STEPS"]
-    t_fine, _ = run(os.path.join(HOST, "gd_fine_sampling"), files[0], 0, steps)
+    t_fine, _ = run(os.path.join(HOST, "gd_fine_sampling"), "--steps", os.environ["FINE_STEPS"], files[0], 0, steps)
     fine = {"steps": int(os.environ["FINE_STEPS"]), "seconds": t_fine}
     if os.environ.get("FINE_AB"):      # (A/B against another build of the program, same restart)
-        fine["seconds_" + os.path.basename(os.environ["FINE_AB"])] = run(os.environ["FINE_AB"], files[0], 0, steps)[0]
+        fine["seconds_" + os.path.basename(os.environ["FINE_AB"])] = run(os.environ["FINE_AB"], "--steps", os.environ["FINE_STEPS"], files[0], 0, steps)[0]
 print(json.dumps({"fine_sampling": fine, "n_beads": n_beads, "replicas": R, "relaxation_steps": cfg["relaxation_steps"], "interphase_steps": steps,
                   "seconds_prepare_spindle_refine_per_file": {k: v / R for k, v in t_prep.items()},
                   "seconds_gd_interphase": t_inter, "bead_steps_per_s_end_to_end": n_beads * R * total_steps / t_inter,
