@@ -70,3 +70,17 @@ def barrier():
 def replica_seed(master_seed, rank):
     """Independent noise streams per rank (the Philox counter carries the local replica index)."""
     return int(master_seed) + 1000003 * int(rank)
+
+
+def bind_to_cpu_share(local_rank, local_world):
+    """Bind this rank to its GPU's share of the CPUs the process may run on (share `local_rank` of `local_world`, contiguous;
+    the GPU box grants 16 CPUs per GPU): the launch threads of eight ranks -- one host thread + one stream per device -- then do
+    not migrate over, or contend with, one another.  Returns the CPUs of the share (the whole set when it cannot be split)."""
+    import os
+    cpus = sorted(os.sched_getaffinity(0))
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    per = len(cpus) // local_world
+    share = cpus[local_rank * per:(local_rank + 1) * per if local_rank < local_world - 1 else len(cpus)]
+    os.sched_setaffinity(0, share)
+    return share

@@ -10,9 +10,16 @@
 // independent: no data moves between the processes, the "gather" is the set of output files.  The launcher itself makes
 // no HIP call (a process that has initialised a GPU must not exec another program on this platform); G defaults to the
 // number of GPU nodes the kernel driver lists.  Exit status: the largest child status.
+// Each driver process is bound to its GPU's share of the CPUs this launcher may run on (share g of G, contiguous): the stepping
+// thread, its packing pool and the writer thread of one GPU do not migrate over, or contend with, those of another
+// (--no-bind turns that off).  When every process has ended the launcher prints one summary line per device:
+//   [farm] gpu g: <n> file(s), status <s>, <t> s, cpus <first>-<last>
+#include <sched.h>
 #include <spawn.h>
 #include <sys/wait.h>
 #include <unistd.h>
+
+#include <chrono>
 
 #include <algorithm>
 #include <cstdio>
@@ -45,23 +52,33 @@ int count_gpus()
 int main(int argc, char **argv)
 {
     int gpus = 0;
-    bool dry = false;
+    bool dry = false, bind = true;
     std::vector<std::string> rest;
     for (int i = 1; i < argc; i++) {
         std::string const a = argv[i];
         if (a == "--gpus" && i + 1 < argc) gpus = std::atoi(argv[++i]);
         else if (a == "--dry-run") dry = true;
+        else if (a == "--no-bind") bind = false;
         else rest.push_back(a);
     }
     if (rest.size() < 2) {
-        std::cerr << "usage: gd_farm [--gpus G] [--dry-run] <driver> <trajectory>...\n";
+        std::cerr << "usage: gd_farm [--gpus G] [--dry-run] [--no-bind] <driver> <trajectory>...\n";
         return 1;
     }
     if (gpus <= 0) gpus = count_gpus();
     std::string const driver = rest[0];
     std::vector<std::string> const files(rest.begin() + 1, rest.end());
     int const groups = (int)std::min<std::size_t>((std::size_t)gpus, files.size());
-    std::vector<pid_t> pids;
+    struct child { pid_t pid = 0; int gpu = 0; std::size_t files = 0; int status = -1; double seconds = 0; int cpu_first = -1, cpu_last = -1; };
+    std::vector<child> kids;
+    // the CPUs this process may run on, in order: child g inherits share g of `groups` (set on the launcher around the spawn)
+    cpu_set_t mine;
+    CPU_ZERO(&mine);
+    std::vector<int> cpus;
+    if (sched_getaffinity(0, sizeof mine, &mine) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &mine)) cpus.push_back(c);
+    bind = bind && (int)cpus.size() >= groups && groups > 1;
+    auto const t0 = std::chrono::steady_clock::now();
     std::size_t at = 0;
     for (int g = 0; g < groups; g++) {
         std::size_t const n = files.size() / groups + ((std::size_t)g < files.size() % groups ? 1 : 0);
@@ -75,18 +92,33 @@ int main(int argc, char **argv)
         std::vector<char *> av;
         for (auto &a : args) av.push_back(a.data());
         av.push_back(nullptr);
-        pid_t pid = 0;
-        int const rc = posix_spawnp(&pid, driver.c_str(), nullptr, nullptr, av.data(), environ);
+        child k;
+        k.gpu = g; k.files = n;
+        if (bind) {
+            std::size_t const per = cpus.size() / (std::size_t)groups, lo = (std::size_t)g * per, hi = g == groups - 1 ? cpus.size() : lo + per;
+            cpu_set_t share;
+            CPU_ZERO(&share);
+            for (std::size_t c = lo; c < hi; c++) CPU_SET(cpus[c], &share);
+            if (sched_setaffinity(0, sizeof share, &share) == 0) { k.cpu_first = cpus[lo]; k.cpu_last = cpus[hi - 1]; }
+        }
+        int const rc = posix_spawnp(&k.pid, driver.c_str(), nullptr, nullptr, av.data(), environ);
+        if (bind) (void)sched_setaffinity(0, sizeof mine, &mine);
         if (rc != 0) { std::cerr << "[farm] cannot start " << driver << ": " << std::strerror(rc) << '\n'; return 127; }
-        pids.push_back(pid);
+        kids.push_back(k);
     }
     int worst = 0;
-    for (pid_t pid : pids) {
+    for (std::size_t left = kids.size(); left > 0; left--) {      // in the order they end: each gets its own wall time
         int status = 0;
-        if (waitpid(pid, &status, 0) < 0) { worst = std::max(worst, 126); continue; }
+        pid_t const pid = waitpid(-1, &status, 0);
+        if (pid < 0) { worst = std::max(worst, 126); break; }
         int const code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
-        if (code != 0) std::cerr << "[farm] process " << pid << " ended with status " << code << '\n';
+        for (auto &k : kids) if (k.pid == pid) { k.status = code; k.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
         worst = std::max(worst, code);
+    }
+    for (auto const &k : kids) {
+        std::cerr << "[farm] gpu " << k.gpu << ": " << k.files << " file(s), status " << k.status << ", " << k.seconds << " s";
+        if (k.cpu_first >= 0) std::cerr << ", cpus " << k.cpu_first << '-' << k.cpu_last;
+        std::cerr << '\n';
     }
     return worst;
 }

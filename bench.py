@@ -281,6 +281,8 @@ def main():
     g = importlib.import_module(PKG)
     wl = importlib.import_module(PKG + ".workloads")
     farm = importlib.import_module(PKG + ".farm")
+    # one host thread + one stream per device: each rank stays on its GPU's share of the host CPUs (before the HIP library starts threads)
+    cpu_share = farm.bind_to_cpu_share(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     hip = g.load(a.lib or None)   # fails loudly if the HIP extension is missing
 
     R, N = a.replicas, a.beads
@@ -370,6 +372,7 @@ def main():
             "metric": "bead-steps/sec on 100kb whole-genome model, 1 GPU and 8-GPU replica farm",
             "value": N * R * world * a.steps / el, "unit": "bead-steps/s",
             "n_gpus": world, "rccl_ranks": world if (grouped and a.dist_backend == "nccl") else 0, "dist_backend": a.dist_backend if grouped else None,
+            "cpus_per_rank": len(cpu_share),
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S-genome-{round(N / 1000)}k (5-sim-genome interphase force field, wall dynamics + scale updates on)",

@@ -6,6 +6,7 @@ compare the files it writes with the same sequence of ABI calls issued from Pyth
 import ctypes as C
 import json
 import os
+import re
 import shutil
 import subprocess
 
@@ -331,6 +332,32 @@ def test_farm_launcher_splits_files_over_gpus(tmp_path):
     ok = subprocess.run([os.path.join(HOST, "gd_farm"), "--gpus", "2", "true", "a", "b"], capture_output=True, text=True)
     bad = subprocess.run([os.path.join(HOST, "gd_farm"), "--gpus", "2", "false", "a", "b"], capture_output=True, text=True)
     assert ok.returncode == 0 and bad.returncode == 1
+
+
+def test_farm_of_two_driver_processes_on_oracle(tmp_path, oracle):
+    """gd_farm --gpus 2 <driver> f0 f1 f2 as it runs on a node with two GPUs, rehearsed with oracle-linked drivers (which ignore
+    --device): two processes (two files batched in one, one in the other), each bound to its share of the launcher's CPUs, one
+    summary line per device, and every file holds exactly what a solo run writes."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "gd_farm"])
+    drv = _make_oracle("gd_interphase", tmp_path)
+    env = _env(os.path.join(ROOT, "oracle"))
+    (tmp_path / "solo").mkdir(); (tmp_path / "farm").mkdir()
+    solo, farm = _batch_case(tmp_path / "solo"), _batch_case(tmp_path / "farm")
+    for d in solo:
+        subprocess.run([str(drv), str(d / "traj.h5")], check=True, capture_output=True, env=env)
+    r = subprocess.run([os.path.join(HOST, "gd_farm"), "--gpus", "2", str(drv), *[str(d / "traj.h5") for d in farm]],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    summary = [ln for ln in r.stderr.splitlines() if ln.startswith("[farm] gpu") and "file(s)" in ln]
+    assert len(summary) == 2 and summary[0].startswith("[farm] gpu 0: 2 file(s), status 0,") and summary[1].startswith("[farm] gpu 1: 1 file(s), status 0,")
+    if len(os.sched_getaffinity(0)) >= 2:
+        shares = [tuple(int(v) for v in re.search(r"cpus (\d+)-(\d+)", ln).groups()) for ln in summary]
+        assert shares[0][1] < shares[1][0]                       # disjoint, contiguous shares
+    for ds, df in zip(solo, farm):
+        fs, ff = _frames(ds), _frames(df)
+        assert fs.keys() == ff.keys() and len(fs) == 7
+        for key in fs:
+            assert np.array_equal(fs[key][0], ff[key][0]) and fs[key][1] == ff[key][1] and fs[key][2] == ff[key][2], key
 
 
 @pytest.mark.gpu
