@@ -68,7 +68,7 @@ class Context(C.Structure):
                 ("semiaxes", C.c_double * 3), ("axial_reaction", C.c_double * 3),
                 ("list_entries", C.c_uint64), ("rebuilds", C.c_uint64), ("rollbacks", C.c_uint64),
                 ("rebuild_interval", C.c_uint32), ("list_radius", C.c_double), ("list_path", C.c_uint32),
-                ("callback_pending", C.c_uint32), ("tile_capacity", C.c_uint32), ("compensated", C.c_uint32)]
+                ("callback_pending", C.c_uint32), ("tile_capacity", C.c_uint32), ("compensated", C.c_uint32), ("largest_tile", C.c_uint32)]
 
 
 class _RunDesc(C.Structure):

@@ -112,6 +112,7 @@ struct gd_system {
     bool has_inner = false; gd_inner_sphere inner{};
     bool has_softcore_bonds = false;
     bool bonds_premixed = false;   // every bond parameter record is unmixed (AB mixing resolved per bond by finalize_topology)
+    bool bonds_all_scaled = false; // every bond parameter record has scale_by_bond_scale set
     uint32_t sw_n = 0; double sw_eps = 0, sw_decay = 1, sw_cut = 0;     // droplet attraction (gd_set_pair_softwell)
     DevBuf<unsigned> sw_targets; DevBuf<double> sw_esum;
     float *h_stage = nullptr;      // pinned host staging for snapshot downloads (R*N*3 floats)
@@ -124,6 +125,11 @@ struct gd_system {
 
     // tuning / cadence
     double skin = 0.75;   // relative to the pair cutoff; 0.65..0.8 are within 3% of each other on S-genome-30k, smaller tiles leave more LDS margin
+    // Width by tile class (class_skin): the wider list (0.9: a third fewer builds) is used wherever its largest tile still fits the
+    // three-block LDS class -- a rule on the state, not on measured times, so a given state always selects the same width.
+    bool skin_fixed = false;       // the caller chose a skin (gd_tuning.skin > 0): keep it
+    uint32_t skin_streak = 0, skin_hold = 0;
+    double skin_next = 0;          // width the next list build moves to (the list in use serves out its interval; 0: none pending)
     uint32_t K = 4, adapt = 1;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
@@ -225,7 +231,7 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
     s->lcount.assign(s->R, 0ull);
     s->ncell_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8ull * s->N, 4096ull), 262144ull);
     if (const char *e = dev_env("GDYN_NEAR_FRAC")) s->near_frac = atof(e);
-    if (const char *e = dev_env("GDYN_SKIN")) s->skin = atof(e);
+    if (const char *e = dev_env("GDYN_SKIN")) { s->skin = atof(e); s->skin_fixed = true; }
     if (dev_env("GDYN_AUTO_SKIN")) s->tuner.enabled = true;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(GD_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -528,6 +534,7 @@ extern "C" int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     o->callback_pending = c.pending ? 1u : 0u;
     o->tile_capacity = (s->list_valid && s->list_tiled) ? s->list_tile_cap : 0u;
     o->compensated = s->comp_last ? 1u : 0u;
+    o->largest_tile = (s->list_valid && s->list_tiled) ? s->last_need_t : 0u;
     return GD_OK;
 }
 
@@ -561,7 +568,8 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
     if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");      // (validated before any state changes)
     if (t->near_fraction < 0 || t->near_fraction > 1) return fail(GD_EINVAL, "gd_set_tuning: near_fraction must be in [0,1]");
-    if (t->skin > 0) s->skin = t->skin;
+    if (t->skin > 0) { s->skin = t->skin; s->skin_fixed = true; }
+    s->skin_streak = 0; s->skin_hold = 0; s->skin_next = 0;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
     s->tuner = gd_system::SkinTuner{};
     s->tuner.enabled = (t->auto_skin != 0 || dev_env("GDYN_AUTO_SKIN")) && t->adapt_interval != 0;          // (a fixed cadence: nothing to select for)
@@ -653,6 +661,8 @@ static int finalize_topology(gd_system *s)
                          p.kind == GD_POT_SEMISPRING ? 0.f : -3.0e38f, p.kind, p.p | (p.q << 8)};
         if (p.kind == GD_POT_SOFTCORE) s->has_softcore_bonds = true;
     }
+    s->bonds_all_scaled = !types.empty();
+    for (auto &p : types) if (!p.scale_by_bond_scale) s->bonds_all_scaled = false;
     // bending: energy of the triplet starting at each bead
     std::vector<double> tE(N, 0.0);
     for (auto &br : s->bends)
@@ -764,7 +774,7 @@ static void fill_common(gd_system *s, StepParams &p)
     }
     p.scaling = ScaleP{s->has_scaling ? 1 : 0, 0, s->bs_init, s->bs_tau, s->bo_init, s->bo_tau, 0.0, 0.0};
     p.btab = s->btab.p; p.nbt = (int)s->n_bond_types; p.has_softcore_bonds = s->has_softcore_bonds ? 1 : 0;
-    p.bonds_premixed = s->bonds_premixed ? 1 : 0;
+    p.bonds_premixed = s->bonds_premixed ? 1 : 0; p.bonds_all_scaled = s->bonds_all_scaled ? 1 : 0;
     p.nps = (int)s->psrc.size();
     for (int q = 0; q < p.nps; q++) {
         p.ps[q].kind = s->psrc[q].kind; p.ps[q].k = (float)s->psrc[q].k; p.ps[q].b = (float)s->psrc[q].b;
@@ -939,9 +949,19 @@ static float list_radius(gd_system *s, const gd_run_desc *run, uint32_t ahead)
     return (float)(cut * (sc + s->skin));
 }
 
+// The width selected by tile class (class_skin) takes over at a list build: interval and radius change together
+static uint32_t interval_for_skin(const gd_system *s, double skin);
+static void take_pending_skin(gd_system *s)
+{
+    if (!(s->skin_next > 0)) return;
+    s->skin = s->skin_next; s->skin_next = 0;
+    s->K = interval_for_skin(s, s->skin); s->K_bad_ttl = 0;
+}
+
 static int ensure_fresh_list(gd_system *s)
 {
     if (s->list_valid && (s->steps_since_build == 0 || s->verified_serial == s->state_serial)) return GD_OK;
+    take_pending_skin(s);
     GDCHK(build_now(s, list_radius(s, nullptr, 0), pair_cutoff(s) > 0));
     s->list_valid = true; s->search_list = false;
     return GD_OK;
@@ -1066,6 +1086,35 @@ static bool want_compensated(const gd_system *s, const gd_run_desc *run)
     return sigma < 64.0 * ulp;
 }
 
+// List width by tile class.  On S-genome-30k x 128 the steady-state cost is flat to 1 % over skins 0.7 ... 0.85 and 2.5 % lower at
+// 0.9 ... 0.95 (interval 20-22 instead of 14: a third fewer builds; `tools/skin_sweep.sh`, profiles/r04_skin_sweep.txt) -- as long as
+// the largest tile stays inside the three-block LDS class (3 312 entries); one class up every block loses a third of its occupancy
+// (S-genome-62k at 0.9: -15 %).  So: the handle starts at 0.75 and moves to 0.9 once the largest tile of the builds, scaled to the
+// wider list (the halo part of a tile grows with the square of the list radius), has fitted the class for three accepted
+// chunks in a row; it moves back when a build at 0.9 leaves the class, and waits 64 chunks before it looks again.  The rule reads
+// the state only (tile sizes are cell counts), never a clock: the same state selects the same width.  Not with a caller-chosen skin
+// (gd_tuning.skin), not while the timing-based selection (gd_tuning.auto_skin) is on.
+static void class_skin(gd_system *s, const gd_run_desc *run)
+{
+    if (s->skin_fixed || !s->adapt || s->tuner.enabled || !s->list_tiled || !s->last_need_t || s->sw_n) return;
+    const double lo = 0.75, hi = 0.9;
+    const double sc = s->pair.scale_by_bead_scale ? bead_scale_bound(s, run, s->K) : 1.0;
+    auto move_to = [&](double skin) {      // takes effect at the next build (take_pending_skin): the list in use stays valid until then
+        s->skin_next = skin; s->skin_streak = 0;
+        if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] list width by tile class: skin %.2f at the next build (largest tile %u)\n", skin, s->last_need_t);
+    };
+    if (s->skin_next > 0) return;
+    if (s->skin < hi - 1e-9) {
+        if (s->skin_hold > 0) { s->skin_hold--; return; }
+        const double ratio = (sc + hi) / (sc + s->skin);
+        // a tile = the block's own slots under three (dz) planes + the halo rows around them: only the halo grows with the cell
+        // cross-section (measured on S-genome-30k: 2 930 entries at 0.75, 3 074 at 0.9)
+        const double own = 3.0 * GD_BLOCK, est = own + std::max(0.0, (double)s->last_need_t - own) * ratio * ratio + 24.0;
+        if (est <= 3312.0 - 24.0 && s->list_tile_cap <= 3312u) { if (++s->skin_streak >= 3) move_to(hi); }
+        else s->skin_streak = 0;
+    } else if (s->skin <= hi + 1e-9 && s->list_tile_cap > 3312u) { move_to(lo); s->skin_hold = 64; }
+}
+
 extern "C" int gd_apply_callback(gd_system *s)
 {
     if (!s) return fail(GD_EINVAL, "gd_apply_callback: NULL system");
@@ -1155,6 +1204,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         bool on_search_list = s->list_valid && s->search_list;
         while (k < chunk) {
             if (!s->list_valid || s->steps_since_build >= s->K) {
+                take_pending_skin(s);
                 hipEvent_t e0 = get_event(s, nev++), e1 = get_event(s, nev++);
                 HIPCHK(hipEventRecord(e0, s->stream));
                 GDCHK(enqueue_build(s, list_radius(s, run, (uint32_t)(k + s->K)), with_list));
@@ -1284,6 +1334,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             if (s->K_bad_ttl > 0) { s->K_bad_ttl--; if (s->K >= s->K_bad) s->K = std::max(1u, s->K_bad - 1); }
         }
         if (with_list) tune_skin(s, ms, chunk, full_interval, false);
+        if (with_list && full_interval) class_skin(s, run);
         done += chunk;
     }
     if (run->steps > 0 && !comp) s->lo_valid = false;      // the positions moved without their residuals
@@ -1368,6 +1419,7 @@ static int search_device(gd_system *s, uint32_t r0, uint32_t nrep, double dcut, 
             // scale over the rest of an interval), like the builds inside gd_run
             gd_run_desc ahead{};
             ahead.timestep = s->last_dt; ahead.flags = s->last_flags;
+            take_pending_skin(s);
             const float rv_force = with_list ? list_radius(s, s->last_dt > 0 ? &ahead : nullptr, s->K) : 0.f;
             const float rv_search = (float)(dcut * (1.0 + 1e-6));
             GDCHK(build_now(s, std::max(rv_force, rv_search), true));

@@ -29,6 +29,19 @@
 
 #include "gdyn_stamps.h"
 
+// Replay builds of k_step (developer timing builds, never shipped: make -C csrc abl N=40 / N=41; tools/replay.sh): the kernel's
+// memory pattern with the arithmetic stripped (N = 40, RP_MEM: records, tile DMA, list and adjacency chunks, LDS gathers, the store;
+// every loaded value is consumed by an empty asm), and its arithmetic with the operands resident (N = 41, RP_ALU: trip counts
+// from the real records, noise, pair / bond / wall arithmetic on register values the compiler cannot fold; no tile DMA, no
+// chunk loads, no LDS gathers).  Same grid, same LDS allocation.  Every hook sits behind the preprocessor: the product source
+// is token for token what it is without them.
+#if GD_ABL == 40 || GD_ABL == 41 || GD_ABL == 43
+#define GD_REPLAY 1
+constexpr bool RP_MEM = (GD_ABL == 40), RP_ALU = (GD_ABL == 41 || GD_ABL == 43);
+#define GD_CONSUME4(v) asm volatile("" :: "v"((v).x), "v"((v).y), "v"((v).z), "v"((v).w))
+#define GD_LAUNDER4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#endif
+
 #define TERM_PAIR 1u
 #define TERM_BOND 2u
 #define TERM_BEND 4u
@@ -222,15 +235,21 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
-__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+// ((x >> 9) + 0.5) 2^-23 as one fma: k 2^-23 + 2^-24 is a 24-bit value, so the single rounding of the fma is exact
+__device__ __forceinline__ float u01(unsigned x) { return fmaf((float)(x >> 9), 1.0f / 8388608.0f, 1.0f / 16777216.0f); }
 
 __device__ __forceinline__ float3 philox_normal3(unsigned long long seed, unsigned bead, long long step, unsigned replica)
 {
     unsigned o0, o1, o2, o3;
     philox4x32_10(bead, (unsigned)((unsigned long long)step & 0xffffffffull), (unsigned)((unsigned long long)step >> 32), replica,
                   (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), o0, o1, o2, o3);
-    // Box-Muller; v_sin/v_cos take their argument in revolutions
-    const float r0 = sqrtf(-2.0f * __logf(u01(o0))), r1 = sqrtf(-2.0f * __logf(u01(o2)));
+    // Box-Muller; v_sin/v_cos take their argument in revolutions.  r = sqrt(-2 ln u) on the hardware log2 and square root (1 ulp
+    // each, u in [2^-24, 1 - 2^-24]: no denormal, no range reduction): -2 ln u = (-2 ln 2) log2 u.  The library forms -- ln through an
+    // extended-precision product with ln 2 and denormal scaling, the IEEE-exact square root with its two correction steps -- are 27
+    // instructions per radius against 3, on a kernel that is bound by VALU issue (profiles/r04_replay.json); the normals stay within
+    // 1e-7 relative of the oracle's (tests/test_parity_gpu.py::test_device_philox_normals_kat: <= 3e-6 absolute)
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(o0)));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(o2)));
     const float t0 = u01(o1), t1 = u01(o3);
     return make_float3(r0 * __builtin_amdgcn_cosf(t0), r0 * __builtin_amdgcn_sinf(t0), r1 * __builtin_amdgcn_cosf(t1));
 }
@@ -284,29 +303,31 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
     o.step = c.step;
     o.bead_scale = (float)c.bead_scale; o.bond_scale = (float)c.bond_scale;
     o.semi[0] = (float)c.semi[0]; o.semi[1] = (float)c.semi[1]; o.semi[2] = (float)c.semi[2];
-    o.inv_bond_scale2 = 1.0f / ((float)c.bond_scale * (float)c.bond_scale);
+    // (hardware reciprocals and square root, 1 ulp: this runs on ONE wave of every block while the other seven wait for it at the
+    // barrier -- the IEEE-exact division is a ten-instruction sequence, a dozen of them were a quarter of the wait)
+    o.inv_bond_scale2 = __builtin_amdgcn_rcpf((float)c.bond_scale * (float)c.bond_scale);
     o.near2 = 0.f; o.w_inv_sa2 = 0.f; o.w_inv_sb2 = 0.f; o.w_ca = 0.f; o.w_cb = 0.f;
     {   // block-uniform constants of the pair term and of the integrator: divisions and the square root once per block
         const float sc = p.pair.scaled ? (float)c.bead_scale : 1.0f;
         const float sa = p.pair.sigma_a * sc, sb = p.pair.sigma_b * sc;
-        o.p_inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f; o.p_inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
+        o.p_inv_sa2 = sa > 0.f ? __builtin_amdgcn_rcpf(sa * sa) : 0.f; o.p_inv_sb2 = sb > 0.f ? __builtin_amdgcn_rcpf(sb * sb) : 0.f;
         o.p_cut = p.pair.cutoff * sc;
-        o.sg_uniform = p.mob_uniform >= 0.f ? sqrtf(2.0f * p.kT * p.mob_uniform * p.dt) : -1.0f;
+        o.sg_uniform = p.mob_uniform >= 0.f ? __builtin_amdgcn_sqrtf(2.0f * p.kT * p.mob_uniform * p.dt) : -1.0f;
     }
     for (int k = 0; k < 3; k++) { o.inv_semi[k] = 0.f; o.inv_semi2[k] = 0.f; }
     if (p.wall.enabled) {
         float smin = 3.4e38f;
         for (int k = 0; k < 3; k++) {
             const float a = (float)c.semi[k];
-            o.inv_semi[k] = 1.0f / a; o.inv_semi2[k] = 1.0f / (a * a); smin = fminf(smin, a);
+            o.inv_semi[k] = __builtin_amdgcn_rcpf(a); o.inv_semi2[k] = o.inv_semi[k] * o.inv_semi[k]; smin = fminf(smin, a);
         }
         const float wsc = p.wall.scaled ? (float)c.bead_scale : 1.0f;
         const float sa = 0.5f * p.wall.sigma_a * wsc, sb = 0.5f * p.wall.sigma_b * wsc;
         // A bead on the level set s E (s = sqrt(C+1) < 1) is at least (1-s) min(a,b,c) away from the surface
         // (E contains s E + (1-s) min(a,b,c) B), so beyond the larger half diameter the wall force is exactly zero
-        const float sthr = 1.0f - fmaxf(sa, sb) / smin;
+        const float sthr = 1.0f - fmaxf(sa, sb) * __builtin_amdgcn_rcpf(smin);
         o.near2 = sthr > 0.f ? sthr * sthr * 0.999f : 0.f;
-        o.w_inv_sa2 = sa > 0.f ? 1.0f / (sa * sa) : 0.f; o.w_inv_sb2 = sb > 0.f ? 1.0f / (sb * sb) : 0.f;
+        o.w_inv_sa2 = sa > 0.f ? __builtin_amdgcn_rcpf(sa * sa) : 0.f; o.w_inv_sb2 = sb > 0.f ? __builtin_amdgcn_rcpf(sb * sb) : 0.f;
         o.w_ca = 6.0f * p.wall.eps_a * o.w_inv_sa2; o.w_cb = 24.0f * p.wall.eps_b * o.w_inv_sb2;
     }
 }
@@ -396,7 +417,11 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                                                  (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
             unsigned base = 0;
 #pragma unroll
+#ifdef GD_REPLAY
+            for (int k = 0; k < (RP_ALU ? 0 : GD_TILE_RANGES); base += tlen[k], k++) {
+#else
             for (int k = 0; k < GD_TILE_RANGES; base += tlen[k], k++) {
+#endif
                 const unsigned len = tlen[k], st = tst[k];
                 for (unsigned q0 = wq; q0 < len; q0 += GD_BLOCK) {      // (wave-uniform loop: scalar control, one compare per lane)
                     if (q0 + lane < len)
@@ -409,8 +434,13 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         // three more loads per thread, unconditionally (every array is allocated for all threads of the block); nothing
         // before the barrier waits for them
         rec = *(const float4 *)((const char *)(p.rec_x0 + tbase) + tid * 16u);
+#ifdef GD_REPLAY
+        if (!RP_ALU)
+#endif
+        {
         adj0 = ((const uint4 *)p.badj)[gw6 * NCB * 64 + lane];
         qa = nt_load((const uint4 *)p.nbr16 + gw6 * NCL * 64 + lane);
+        }
         GD_STAMP(8);      // per-bead loads issued
     } else {
         for (unsigned t = tid; t < (unsigned)p.nbt; t += GD_BLOCK) s_bt[t] = p.btab[t];
@@ -443,15 +473,26 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     // and the per-bead loads are in flight (the step index comes from a uniform scalar load).  Tiled path: whether the
     // thread owns a bead is not known yet (that is in the build-position record); threads without one have bead id 0.
     float3 z = make_float3(0.f, 0.f, 0.f);
-    if (MODE == GD_MODE_STEP && (TILED ? oid != GD_REC_ID_MASK : valid) && p.kT > 0.f) {
-        if (p.noise_mode == NOISE_PHILOX) {
-            const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
-            z = p.seeds ? philox_normal3(p.seeds[r], oid, step_now + 1, 0u) : philox_normal3(p.seed, oid, step_now + 1, r);
-        } else if (p.noise_mode == NOISE_HOST) {
-            const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
-            z = make_float3(h[0], h[1], h[2]);
+    auto draw_noise = [&]() {
+#ifdef GD_REPLAY
+        if (RP_MEM) return;
+#endif
+        if (MODE == GD_MODE_STEP && (TILED ? oid != GD_REC_ID_MASK : valid) && p.kT > 0.f) {
+            if (p.noise_mode == NOISE_PHILOX) {
+                const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
+                z = p.seeds ? philox_normal3(p.seeds[r], oid, step_now + 1, 0u) : philox_normal3(p.seed, oid, step_now + 1, r);
+            } else if (p.noise_mode == NOISE_HOST) {
+                const float *h = p.host_noise + ((size_t)r * p.N + oid) * 3;
+                z = make_float3(h[0], h[1], h[2]);
+            }
         }
-    }
+    };
+    // Wave 0 of a tiled stepping block carries the block's context work (pending callback, float constants) in front of the barrier,
+    // on top of what every wave does there; the other seven wait for it (section stamps: 12 % of a wave's life).  Its noise is needed
+    // by the update at the very end only: wave 0 draws it behind the barrier, so that what it does in front of the barrier is about
+    // what the others do (record, DMA issue, noise | record, DMA issue, context).
+    const bool noise_late = TILED && MODE == GD_MODE_STEP && wid == 0;
+    if (!noise_late) draw_noise();
     GD_STAMP_USE3(z.x, z.y, z.z);
     GD_STAMP(10);     // noise
     // wave 0: pending callback + float copy of the context for the block.  After the noise: its vector loads sit behind the
@@ -467,6 +508,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     GD_STAMP(0);      // prologue: loads issued, tile DMA issued, noise
     __syncthreads();
     GD_STAMP(1);      // barrier (tile arrival)
+    if (noise_late) draw_noise();
     if (TILED) {
         valid = oid != GD_REC_ID_MASK;
         slot = valid ? blk * GD_BLOCK + local : p.N;
@@ -474,7 +516,11 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         if (valid) {
             // (a truncated tile holds other beads at these indices: take the bead's position from memory, so that the
             // rolled-back chunk at least leaves plausible positions to the builds that follow in it)
+#if GD_ABL == 41 || GD_ABL == 43
+            xi4 = p.pos_in[g];
+#else
             xi4 = tile_ok ? s_tile[own_base + local] : p.pos_in[g];
+#endif
             x0 = rec;
             if (MODE == GD_MODE_STEP && p.mob_uniform < 0.f) mu = p.mob[g];
         }
@@ -536,7 +582,16 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             // (tiled: chunk c of the thread = wave base + c KiB + lane x 16 bytes -- a scalar base and a 32-bit offset, no per-lane
             // 64-bit pointer lives across the loop)
             const char *lst_w = (const char *)((const uint4 *)p.nbr16 + gw6 * NCL * 64);
+#ifdef GD_REPLAY
+            float4 rp_x = make_float4(xi.x + 0.11f, xi.y - 0.07f, xi.z + 0.05f, xi4.w);      // (RP_ALU: the neighbour every entry stands for)
+            auto chunk = [&](unsigned c) -> uint4 {
+                if (RP_ALU) { const unsigned e2 = (((own_base + local) << 4) & 0xffffu) * 0x10001u; return make_uint4(e2, e2, e2, e2 + c * 0u); }
+                return nt_load((const uint4 *)(lst_w + (c * 1024u + lane * 16u)));
+            };
+            if (RP_ALU) qa = chunk(0u);
+#else
             auto chunk = [&](unsigned c) -> uint4 { return nt_load((const uint4 *)(lst_w + (c * 1024u + lane * 16u))); };
+#endif
             if (TILED && nchA == 0u && nch != 0u) qa = chunk(NCL - 1u);      // (no near chunk: the first one is a far chunk)
             for (unsigned k0 = 0; k0 < cntp; k0 += GD_UNROLL) {
                 unsigned jj[GD_UNROLL];
@@ -564,12 +619,18 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                 if (GD_HALF != (int)GD_UNROLL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = uh; u < uh + GD_HALF; u++) {
+#ifdef GD_REPLAY
+                    if (RP_ALU) { GD_LAUNDER4(rp_x); xjv[u] = rp_x; continue; }
+#endif
                     xjv[u] = !TILED ? rpos[jj[u]] : S16 ? *(const float4 *)((const char *)s_tile + jj[u]) : s_tile[jj[u]];
                 }
 #pragma unroll
                 for (int u = uh; u < uh + GD_HALF; u++) {
                     const float4 xj = xjv[u];
                     const unsigned j = jj[u];
+#ifdef GD_REPLAY
+                    if (RP_MEM) { GD_CONSUME4(xj); continue; }
+#endif
                     float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
                     if (PERIODIC) d = min_image(d, p.box, p.inv_box);
                     const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
@@ -615,7 +676,12 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                 const unsigned own_idx = own_base + local;
                 for (unsigned k0 = 0; k0 < deg; k0 += 4) {
                     // (chunks beyond the first -- a bead with more than four bonds -- by scalar base + 32-bit lane offset, like the lists)
+#ifdef GD_REPLAY
+                    uint4 aq = (k0 == 0 || RP_ALU) ? adj0 : *(const uint4 *)((const char *)((const uint4 *)p.badj + gw6 * NCB * 64) + ((k0 >> 2) * 1024u + lane * 16u));
+                    if (RP_ALU) { const unsigned el = GD_ADJ_LOCAL | own_idx; aq = make_uint4(el, el, el, el); }
+#else
                     const uint4 aq = k0 == 0 ? adj0 : *(const uint4 *)((const char *)((const uint4 *)p.badj + gw6 * NCB * 64) + ((k0 >> 2) * 1024u + lane * 16u));
+#endif
                     const unsigned ents4[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
@@ -629,6 +695,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                             on[u] = k0 + 2u * h + u < deg;
                             const unsigned e = on[u] ? ents4[2 * h + u] : GD_ADJ_LOCAL;
                             const bool loc = (e & GD_ADJ_LOCAL) != 0u;
+#ifdef GD_REPLAY
+                            if (RP_ALU) { float4 t = make_float4(xi.x + 0.13f, xi.y + 0.09f, xi.z - 0.11f, xi4.w); GD_LAUNDER4(t); xjs[u] = t; } else
+#endif
                             xjs[u] = s_tile[(on[u] && loc) ? (e & GD_ADJ_MASK) : own_idx];
                             ty[u] = (e >> GD_ADJ_SHIFT) & (GD_MAX_BOND_TYPES - 1);
                             ta[u] = *(const float4 *)&s_bt[ty[u]];
@@ -643,6 +712,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
 #pragma unroll
                         for (int u = 0; u < 2; u++) {
                             const float4 xj = xjs[u];
+#ifdef GD_REPLAY
+                            if (RP_MEM) { GD_CONSUME4(xj); GD_CONSUME4(ta[u]); asm volatile("" :: "v"(tb[u].x), "v"(tb[u].y)); continue; }
+#endif
                             const unsigned flags = __float_as_uint(tb[u].x);
                             float3 d = make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z);
                             if (PERIODIC && (flags & 4u)) d = min_image(d, p.box, p.inv_box);
@@ -655,9 +727,11 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                                 const float a = mixed ? 0.5f * (abi.x + abj.x) : 1.0f, b = mixed ? 0.5f * (abi.y + abj.y) : 0.0f;
                                 K = a * ta[u].x + b * ta[u].y; l = a * ta[u].z + b * ta[u].w;
                             }
-                            K *= scaled ? inv_bs2 : 1.0f; l *= scaled ? s_ctx.bond_scale : 1.0f;
+                            if (p.bonds_all_scaled) { K *= inv_bs2; l *= s_ctx.bond_scale; }      // (uniform: every bond set of the model scales with bond_scale)
+                            else { K *= scaled ? inv_bs2 : 1.0f; l *= scaled ? s_ctx.bond_scale : 1.0f; }
                             // harmonic / spring / semispring in one form: elongation x = r - l clamped from below
-                            const float inv_d = r2 > 0.0f ? __builtin_amdgcn_rsqf(r2) : 0.0f;     // hardware rsq, 1 ulp
+                            // (r2 = 0 -- a padding entry, coincident beads -- gives x = -l and a finite fr on d = 0: zero force, like the guarded form)
+                            const float inv_d = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));     // hardware rsq, 1 ulp
                             const float x = fmaxf(fmaf(r2, inv_d, -l), tb[u].y);
                             float fr = -K * x * inv_d, e = 0.f;
                             if (MODE == GD_MODE_ENERGY) e = 0.5f * K * x * x;
@@ -775,6 +849,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         GD_STAMP(4);  // bending + point sources
         // ---- ellipsoid wall (a9): second-order nearest-surface construction
         // (5-sim-genome/src/analyze_lamina/geometry.py:13-28), conjugate form u = C/(B+sqrt(B^2-AC)).
+#ifdef GD_REPLAY
+        if (!RP_MEM)
+#endif
         if (p.wall.enabled && (mask & TERM_WALL)) {
             const float ia = s_ctx.inv_semi2[0], ib = s_ctx.inv_semi2[1], ic = s_ctx.inv_semi2[2];
             const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);

@@ -7,7 +7,7 @@
 #define GD_ABL 0
 #endif
 
-#if GD_ABL == 30
+#if GD_ABL == 30 || GD_ABL == 43      // (43: the ALU replay of gdyn_kernels.hip with the section stamps: where the arithmetic's issue time goes)
 #define GD_STAMP_BEGIN() unsigned long long tprev_ = __builtin_amdgcn_s_memtime(), acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define GD_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] = now_ - tprev_; tprev_ = now_; } while (0)
 #define GD_STAMP_USE3(a, b, c) asm volatile("" :: "v"(a), "v"(b), "v"(c))

@@ -166,6 +166,7 @@ struct StepParams {
     const uint2 *rec_mo;
     int has_softcore_bonds;             // some bond set is a soft core (the glue pairs of the 1 kb model): rare path
     int bonds_premixed;                 // no bond record asks for AB mixing (the host resolved it per bond): K = ka, l = la
+    int bonds_all_scaled;               // every bond record scales with bond_scale (the genome models): no per-bond select
     const unsigned *badj;               // chunked like the pair lists, 4 entries per chunk
     const int4 *chain;                  // slots of (i-2, i-1, i+1, i+2) or -1
     // context

@@ -227,6 +227,8 @@ typedef struct {
     uint32_t callback_pending;   /* 1: the state updates of callback(step + 1) are pending (GD_RUN_DEFER_CALLBACK) */
     uint32_t tile_capacity;      /* LDS-tiled lists: beads of LDS per block the list in use was built for (0 on the generic path) */
     uint32_t compensated;        /* 1: the last gd_run stepped with the compensated position update (gd_run, below) */
+    uint32_t largest_tile;       /* LDS-tiled lists: beads in the largest tile of the last build, over all replicas (what decides the
+                                    tile class, and with it the list width the handle selects) */
 } gd_context;
 
 int gd_get_context(gd_system *sys, uint32_t replica, gd_context *out);

@@ -287,6 +287,7 @@ def test_short_runs_do_not_inflate_the_rebuild_interval(hip):
     PARTIAL interval and must not be used to lengthen the interval -- the next long run would violate the skin
     and be rolled back."""
     s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=8)
+    s.set_tuning(skin=0.75)                              # (a fixed width: the selection by tile class would move the interval with it)
     dt, kT = info["timestep"], info["temperature"]
     flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
     s.begin_phase()
@@ -820,7 +821,7 @@ def test_adapted_interval_trajectory_matches_oracle(hip, oracle):
     sh, info, flags = _adapted_state(hip, R)
     c0 = sh.context()
     K = c0.rebuild_interval
-    assert 8 <= K <= 24 and c0.list_path == 2, (K, c0.list_path)
+    assert 8 <= K <= 30 and c0.list_path == 2, (K, c0.list_path)
     so, _ = wl.genome_interphase(oracle, n_beads=30000, n_replicas=R)
     so.set_positions(sh.positions())
     for r in range(R):
@@ -994,7 +995,7 @@ def test_benchmark_launch_shape_matches_oracle(hip, oracle):
     R, picks = 128, (0, 63, 127)
     sh, info, flags = _adapted_state(hip, R, steps=600)
     c0 = sh.context()
-    assert c0.list_path == 2 and 8 <= c0.rebuild_interval <= 24, (c0.list_path, c0.rebuild_interval)
+    assert c0.list_path == 2 and 8 <= c0.rebuild_interval <= 30, (c0.list_path, c0.rebuild_interval)
     x0 = sh.positions()
     ctx = {r: sh.context(r) for r in picks}
     Fh = sh.forces()
@@ -1090,3 +1091,30 @@ def test_fp64_positions_survive_the_boundary_and_compensated_runs_on_both_paths(
         assert sh.context().compensated == 0
         xs = sh.positions()
         assert np.array_equal(xs, xs.astype(np.float32).astype(np.float64))
+
+
+def test_list_width_follows_the_tile_class(hip, oracle):
+    """The default list width is a rule on the state (gdyn_capi.hip, class_skin): 0.9 x cutoff where the largest tile of the wider
+    list fits the three-block LDS class (S-genome-30k), 0.75 where it does not (S-genome-62k); a caller-chosen skin stays.  The
+    width changes cost only: forces on the state that the wide list produced match the oracle."""
+    cut = 0.30
+    for n_beads, R, wide in ((30000, 16, True), (62178, 8, False)):
+        s, info = wl.genome_interphase(hip, n_beads=n_beads, n_replicas=R)
+        s.begin_phase()
+        s.run(1500, info["timestep"], info["temperature"], seed=SEED + 9, flags=0)
+        c = s.context()
+        assert c.list_path == 2 and c.tile_capacity == 3312 or not wide, (c.list_path, c.tile_capacity)
+        assert abs(c.list_radius - cut * (1.0 + (0.9 if wide else 0.75))) < 1e-3, (n_beads, c.list_radius, c.largest_tile, c.tile_capacity)
+        if wide:
+            assert c.rebuild_interval >= 17, c.rebuild_interval
+            x = s.positions()
+            so, _ = wl.genome_interphase(oracle, n_beads=n_beads, n_replicas=1)
+            so.set_positions(x[3][None])
+            Fo = so.forces()[0]
+            assert np.abs(s.forces()[3] - Fo).max() <= FORCE_RTOL * np.abs(Fo).max()
+        s.close()
+    s, info = wl.genome_interphase(hip, n_beads=30000, n_replicas=16)
+    s.set_tuning(skin=0.75)
+    s.begin_phase()
+    s.run(1500, info["timestep"], info["temperature"], seed=SEED + 9, flags=0)
+    assert abs(s.context().list_radius - cut * 1.75) < 1e-3
