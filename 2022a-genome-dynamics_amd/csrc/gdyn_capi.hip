@@ -130,6 +130,8 @@ struct gd_system {
     bool skin_fixed = false;       // the caller chose a skin (gd_tuning.skin > 0): keep it
     uint32_t skin_streak = 0, skin_hold = 0;
     double skin_next = 0;          // width the next list build moves to (the list in use serves out its interval; 0: none pending)
+    double skin_dense_from = 0;    // > 0: the width was narrowed because a build met a dense state (dense_guard); the width to return to
+    uint32_t last_need_w = 0;      // longest list (entries, padded) the last build reported
     uint32_t K = 4, adapt = 1;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
@@ -863,6 +865,27 @@ static unsigned pick_tile_cap(unsigned need)
     return need;     // > 8192: the caller falls back to the generic path
 }
 
+// A build that meets a dense state -- the spline-refined start of the pipeline is a globule in which some beads have 1 500
+// neighbours inside the default list radius -- must not size every row of the handle for it: the list width is narrowed so that
+// the longest list, which grows with the cube of the radius, comes down to ~384 entries (at least a skin of 0.15 x cutoff; such
+// states move fast, their rebuild interval is a few steps at any width).  class_skin returns to the default width once the
+// longest list, scaled back to it, is short again.  Not with a caller-chosen skin.
+static void dense_guard(gd_system *s, unsigned need_w)
+{
+    if (s->skin_fixed || need_w <= 512u || !(s->rv > 0)) return;
+    const double cut = pair_cutoff(s);
+    if (!(cut > 0)) return;
+    const double sc = s->rv / cut - s->skin;                       // bead-scale part of the radius the build used
+    const double r_new = s->rv * std::cbrt(384.0 / (double)need_w);
+    const double skin_new = std::max(0.15, r_new / cut - sc);
+    if (skin_new < s->skin - 1e-9) {
+        if (!(s->skin_dense_from > 0)) s->skin_dense_from = s->skin;
+        s->skin = skin_new; s->skin_next = 0; s->K = std::max(1u, std::min(s->K, 4u)); s->a2_ema = 0;
+        s->W = 448;      // (the narrowed list is predicted at 384 entries; a miss is one more exactly sized build)
+        if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state (longest list %u): skin %.3f\n", need_w, skin_new);
+    }
+}
+
 // React to list-width / tile-capacity overflow flags: widen the list, enlarge the LDS tile or
 // fall back to the generic path. Returns true when a build has to be redone.
 static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
@@ -873,6 +896,7 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         tover |= f[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] != 0; need_t = std::max(need_t, f[r * GD_NFLAGS + GD_FLAG_NEED_TILE]);
     }
     if (need_t > 0 && need_t < (1u << 20)) s->last_need_t = need_t;
+    if (need_w > 0) s->last_need_w = need_w;
     if (!tover && !over && s->list_tiled && need_t > 0) {
         // size the LDS tile to what the builds actually need (more resident blocks per CU)
         // LDS capacity is a step function of the tile size: k_step keeps 3 / 2 / 1 blocks (6 / 4 / 2 waves per SIMD)
@@ -894,7 +918,15 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         if (cap <= cap_max) { s->tile_cap = cap; s->tile_hold = 4; }
         else { s->tiled_ok = false; s->tiled_off = 1; }     // too dense for one tile: generic path (retried later with back-off)
     }
-    if (over) s->W = std::max(need_w + need_w / 4 + 4, s->W * 2);
+    if (over) {
+        // The overflowing build has counted the longest list exactly (a row keeps counting past its width): the next build gets
+        // that width with 6 % to spare -- not a doubling, and not beyond what a tiled row can hold while the need still fits one
+        // (a width beyond GD_TILED_MAX_W sends the handle to generic lists at 4 bytes per entry: the 29 GB allocation of round 3).
+        unsigned w = need_w + need_w / 16 + 8;
+        if (need_w <= GD_TILED_MAX_W) w = std::min(w, GD_TILED_MAX_W);
+        s->W = std::max(w, s->W + 8);
+        dense_guard(s, need_w);
+    }
     else if (!tover && need_w > 0) {
         // the longest list is reported by every build: give the row width back when a dense transient has passed
         const unsigned want_w = std::max(64u, (need_w + need_w / 4 + 16 + GD_UNROLL - 1) & ~(GD_UNROLL - 1));
@@ -1096,6 +1128,17 @@ static bool want_compensated(const gd_system *s, const gd_run_desc *run)
 // (gd_tuning.skin), not while the timing-based selection (gd_tuning.auto_skin) is on.
 static void class_skin(gd_system *s, const gd_run_desc *run)
 {
+    if (s->skin_dense_from > 0 && !s->skin_fixed) {
+        // back from the narrow width of a dense state (dense_guard) once the longest list, scaled to the width it left, is short
+        // again; the timing-based selection, when enabled, starts from there
+        const unsigned need_w = s->last_need_w;
+        const double cut = pair_cutoff(s), sc0 = s->rv / cut - s->skin, ratio = (sc0 + s->skin_dense_from) / (sc0 + s->skin);
+        if (need_w > 0 && (double)need_w * ratio * ratio * ratio <= 256.0 && !(s->skin_next > 0)) {
+            s->skin_next = s->skin_dense_from; s->skin_dense_from = 0;
+            if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state has passed (longest list %u): skin %.3f at the next build\n", need_w, s->skin_next);
+        }
+        return;
+    }
     if (s->skin_fixed || !s->adapt || s->tuner.enabled || !s->list_tiled || !s->last_need_t || s->sw_n) return;
     const double lo = 0.75, hi = 0.9;
     const double sc = s->pair.scale_by_bead_scale ? bead_scale_bound(s, run, s->K) : 1.0;

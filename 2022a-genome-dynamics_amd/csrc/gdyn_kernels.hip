@@ -321,6 +321,11 @@ __device__ __forceinline__ void fill_ctxf(CtxF &o, const DevCtx &c, const StepPa
             const float a = (float)c.semi[k];
             o.inv_semi[k] = __builtin_amdgcn_rcpf(a); o.inv_semi2[k] = o.inv_semi[k] * o.inv_semi[k]; smin = fminf(smin, a);
         }
+        {
+            const double a2 = c.semi[0] * c.semi[0], b2 = c.semi[1] * c.semi[1], c2 = c.semi[2] * c.semi[2];
+            o.w_q[0] = b2 * c2; o.w_q[1] = a2 * c2; o.w_q[2] = a2 * b2; o.w_q[3] = a2 * o.w_q[0];
+            o.w_inv_q3 = __builtin_amdgcn_rcpf((float)o.w_q[3]);
+        }
         const float wsc = p.wall.scaled ? (float)c.bead_scale : 1.0f;
         const float sa = 0.5f * p.wall.sigma_a * wsc, sb = 0.5f * p.wall.sigma_b * wsc;
         // A bead on the level set s E (s = sqrt(C+1) < 1) is at least (1-s) min(a,b,c) away from the surface
@@ -855,9 +860,13 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         if (p.wall.enabled && (mask & TERM_WALL)) {
             const float ia = s_ctx.inv_semi2[0], ib = s_ctx.inv_semi2[1], ic = s_ctx.inv_semi2[2];
             const float3 s1 = make_float3(xi.x * ia, xi.y * ib, xi.z * ic);
-            const float C1 = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z, C = C1 - 1.0f;
+            const float C1 = xi.x * s1.x + xi.y * s1.y + xi.z * s1.z;
             // waves of interior beads (the slots are cell-sorted) skip the nearest-point construction altogether
             if (__builtin_amdgcn_ballot_w64(C1 >= s_ctx.near2) != 0ull) {
+            // C = C1 - 1 is a difference of two numbers near 1 for every bead the wall acts on (|C| < 0.05): its numerator in fp64
+            // (full-rate on this chip) from the fp64 semiaxes; everything downstream is a product, fp32 is enough there
+            const double xd = (double)xi.x, yd = (double)xi.y, zd = (double)xi.z;
+            const float C = (float)fma(xd * xd, s_ctx.w_q[0], fma(yd * yd, s_ctx.w_q[1], fma(zd * zd, s_ctx.w_q[2], -s_ctx.w_q[3]))) * s_ctx.w_inv_q3;
             const float B = s1.x * s1.x + s1.y * s1.y + s1.z * s1.z;
             const float A = s1.x * s1.x * ia + s1.y * s1.y * ib + s1.z * s1.z * ic;
             // (hardware sqrt / rcp, 1 ulp: the IEEE-exact sequences are ~10 instructions each)
@@ -1042,7 +1051,9 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
     // the blocks whose tile fits 3 312 with that much LDS, then the rest; each block returns at once from the launch it is not in.
     // The same one class up: tiles beyond 5 072 entries (dense states: one block per CU) next to tiles that fit two blocks per CU.
     // (Stepping only: force / energy evaluations are rare and run in the larger class.)
-    const unsigned split_at = !p.tiled ? 0u : (s16 && p.tile_cap > 3312u) ? 3312u : (!s16 && p.tile_cap > 5072u) ? 5072u : 0u;
+    // (Plain-index lists -- tiles of 4 096 entries and more, the periodic 1 kb model -- split the same way at 3 312: their kernel fits
+    // 80 registers, so the blocks with small tiles run three to a CU next to the few large ones.)
+    const unsigned split_at = !p.tiled ? 0u : (s16 && p.tile_cap > 3312u) ? 3312u : (!s16 && p.tile_cap > 5072u) ? 5072u : (!s16 && p.tile_cap > 3312u) ? 3312u : 0u;
     if (MODE == GD_MODE_STEP && split_at) {
         static bool once_split = false;
         if (!once_split) {
@@ -1488,6 +1499,18 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         unsigned bin = 63u;                                        // slots past N: last
         if (slot < p.N) bin = 62u - min((unsigned)p.len_prev[(size_t)r * p.N + o_pre], 62u);
         __syncthreads();
+        if (PERIODIC) {
+            // Periodic boxes: wrap the staged tile into [0, L) in place (coordinates are kept unwrapped in memory: a chain that has
+            // diffused around the box brings every periodic image into one cell).  With every candidate of a (row, x-interval) in
+            // the same image relative to the bead, the minimum image of the sweep below is ONE shift of the bead per interval
+            // instead of three round-to-nearest per candidate (15 -> 9 instructions per test; the wrap costs ~6 entries per thread).
+            const unsigned total = s_tdesc.total;
+            for (unsigned t = threadIdx.x; t < total; t += GD_BLOCK) {
+                float4 x = s_tile[t];
+                x.x -= p.box[0] * floorf(x.x * p.inv_box[0]); x.y -= p.box[1] * floorf(x.y * p.inv_box[1]); x.z -= p.box[2] * floorf(x.z * p.inv_box[2]);
+                s_tile[t] = x;
+            }
+        }
         const unsigned rank = atomicAdd(&s_hist[bin], 1u);
         __syncthreads();
         unsigned incl = s_hist[lane];
@@ -1591,9 +1614,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 if (cntB % 8u == 0) { if (((cnt + 7u) & ~7u) + cntB <= p.W) lst[(size_t)(NC - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3); }
             };
             if (TILED && PERIODIC) {
-                // periodic tile = whole rows: for each of the 9 wrapped (dz,dy) rows the x-window cx-1..cx+1 is one
-                // slot interval, or two when it wraps around the row end; candidates are compared under the minimum image
+                // periodic tile = whole rows: for each of the 9 wrapped (dz,dy) rows the x-window cx-1..cx+1 is one slot interval, or
+                // two when it wraps around the row end.  The tile holds wrapped coordinates (above), so the candidates of one
+                // (row, interval) are all in the same periodic image relative to the bead: the bead, wrapped the same way, is shifted
+                // by that image once and the tests are the open-box ones.  (Exact while cells are at least the list radius wide and
+                // the grid has three cells per axis: k_tiles sends smaller grids to the generic path.)
                 const int nx = gp.nc[0], ny = gp.nc[1], nz = gp.nc[2];
+                const float3 xw = make_float3(xi.x - p.box[0] * floorf(xi.x * p.inv_box[0]), xi.y - p.box[1] * floorf(xi.y * p.inv_box[1]),
+                                              xi.z - p.box[2] * floorf(xi.z * p.inv_box[2]));
                 unsigned pb[2 * GD_TILE_RANGES], pe[2 * GD_TILE_RANGES];
 #pragma unroll
                 for (int k = 0; k < GD_TILE_RANGES; k++) {
@@ -1611,6 +1639,12 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                         if (!to_local(b, lb)) { p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u; continue; }   // (cannot happen: the row is staged)
                         const unsigned le = lb + (e - b);
                         const unsigned self_l = lb + (slot - b);
+                        // image of this interval: rows below / above the box in y and z; in x the first interval of a bead in the last
+                        // cell is cell 0 (one period up), the second interval of a bead in cell 0 is the last cell (one period down)
+                        const int y0 = cy + (k2 >> 1) % 3 - 1, z0 = cz + (k2 >> 1) / 3 - 1;
+                        const float ax = xw.x + ((k2 & 1) ? (cx == 0 ? p.box[0] : 0.f) : (cx == nx - 1 ? -p.box[0] : 0.f));
+                        const float ay = xw.y + (y0 < 0 ? p.box[1] : y0 >= ny ? -p.box[1] : 0.f);
+                        const float az = xw.z + (z0 < 0 ? p.box[2] : z0 >= nz ? -p.box[2] : 0.f);
                         for (unsigned j0 = lb; j0 < le; j0 += 32) {
                             const unsigned n = min(32u, le - j0);
                             unsigned m = 0, mn = 0;
@@ -1619,8 +1653,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 #pragma unroll
                                 for (int u = 0; u < 4; u++) {
                                     const float4 xj = cj[u];
-                                    const float3 d = min_image(make_float3(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z), p.box, p.inv_box);
-                                    const float t = fmaf(d.z, d.z, fmaf(d.y, d.y, fmaf(d.x, d.x, -rv2)));
+                                    const float dx = ax - xj.x, dy = ay - xj.y, dz = az - xj.z;
+                                    const float t = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, -rv2)));
                                     m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);
                                     mn = __builtin_amdgcn_alignbit(mn, __float_as_uint(t + dnear), 31);
                                 }

@@ -80,6 +80,11 @@ struct CtxF {                   // float copy of DevCtx + block-uniform wall con
     float w_inv_sa2, w_inv_sb2, w_ca, w_cb;     // soft wall (half diameters, bead scale): 1/s^2, 6 eps_a / sa^2, 24 eps_b / sb^2
     float p_inv_sa2, p_inv_sb2, p_cut;          // pair potential at the current bead scale: 1/sigma^2 of both cores, cutoff
     float sg_uniform;                           // sqrt(2 mu kT dt) for the uniform mobility (< 0: per-bead mobilities)
+    // the wall's level-set value C = x^2/a^2 + y^2/b^2 + z^2/c^2 - 1 without its cancellation (beads in reach of the wall have
+    // |C| < 0.05: in fp32 the difference of two numbers near 1 loses three digits): numerator x^2 b^2c^2 + y^2 a^2c^2 + z^2 a^2b^2 -
+    // a^2b^2c^2 in fp64 from the fp64 semiaxes, times the fp32 reciprocal of a^2b^2c^2
+    float w_inv_q3;                             // 1 / (a^2 b^2 c^2)
+    double w_q[4];                              // b^2c^2, a^2c^2, a^2b^2, a^2b^2c^2
 };
 
 struct GridP {                  // per replica cell grid of the last list build

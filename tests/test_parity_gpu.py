@@ -1061,7 +1061,7 @@ def test_fine_timestep_displacement_field_matches_oracle(hip, oracle, n_beads):
             assert errs[tag].max() <= 1e-3 * med, (errs[tag].max(), med)
             assert np.median(errs[tag]) <= 1e-5 * med
             assert np.all(dh[moving] != 0) and np.all(np.sign(dh[moving]) == np.sign(do[moving]))
-            assert abs(sh.context().semiaxes[0] - so.context().semiaxes[0]) <= 1e-10
+            assert abs(sh.context().semiaxes[0] - so.context().semiaxes[0]) <= 1e-9        # (a semiaxis of 6 ... 8 moved by ~1e-6 in these steps)
         sh.close()
     assert errs["plain"].max() > 20 * 1e-3 * med and np.median(errs["plain"]) > 1e-3 * med
 
@@ -1101,7 +1101,11 @@ def test_list_width_follows_the_tile_class(hip, oracle):
     for n_beads, R, wide in ((30000, 16, True), (62178, 8, False)):
         s, info = wl.genome_interphase(hip, n_beads=n_beads, n_replicas=R)
         s.begin_phase()
-        s.run(1500, info["timestep"], info["temperature"], seed=SEED + 9, flags=0)
+        s.run(3000, info["timestep"], info["temperature"], seed=SEED + 9, flags=0)
+        for _ in range(4):      # (the random-walk start is denser than the relaxed state: its tiles shrink into the class as it relaxes)
+            if not wide or s.context().list_radius > cut * 1.8:
+                break
+            s.run(1500, info["timestep"], info["temperature"], seed=SEED + 9, flags=0)
         c = s.context()
         assert c.list_path == 2 and c.tile_capacity == 3312 or not wide, (c.list_path, c.tile_capacity)
         assert abs(c.list_radius - cut * (1.0 + (0.9 if wide else 0.75))) < 1e-3, (n_beads, c.list_radius, c.largest_tile, c.tile_capacity)

@@ -2,7 +2,7 @@
 # tools/profile_round.sh <tag>: the round's evidence in one GPU call -- relaxed state, rocprofv3 kernel stats, PMC passes
 # (separate, no tracing domains), plain bench lines; then the same for S-1kb-250k x 16.  Everything lands in gpurun_out/<tag>_*;
 # copy what is judged to profiles/ (tools/traffic_json.py writes profiles/<tag>_traffic*.json).
-tag=${1:-r03}
+tag=${1:-r04}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 python3 $root/bench.py --save-state /tmp/state.npy > /dev/null 2>&1
@@ -26,6 +26,14 @@ cp $out/pmc_${tag}_1kb/summary.txt $out/${tag}_1kb_bench_pmc_summary.txt
 unset STATE_IN
 echo "[profile] 1kb done"
 cd $root
+# ---- what bounds k_step: replay builds (memory pattern only / arithmetic only), section stamps, VALU issue rates (developer builds,
+# built in-tree before the call: make -C csrc dev abl N=30 && make abl N=40 && make abl N=41 && make abl N=43; tools/ubench/valu_rate)
+if [ -f 2022a-genome-dynamics_amd/csrc/libgdyn_abl41.so ]; then
+  python3 tools/replay.py $out/${tag}_replay.json > /dev/null 2> $out/${tag}_replay.err
+  rm -f $out/${tag}_sections.txt; bash tools/sections.sh $out/${tag}_sections.txt
+  [ -x tools/ubench/valu_rate ] && ./tools/ubench/valu_rate > $out/${tag}_valu_rate.txt 2>&1
+  echo "[profile] replay done"
+fi
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "[profile] driver-line bench done"
 python3 bench.py --no-cpu-baseline --no-extra > $out/${tag}_bench_2000steps.json 2> $out/${tag}_bench_2000steps.err
