@@ -132,6 +132,7 @@ struct gd_system {
     double skin_next = 0;          // width the next list build moves to (the list in use serves out its interval; 0: none pending)
     double skin_dense_from = 0;    // > 0: the width was narrowed because a build met a dense state (dense_guard); the width to return to
     uint32_t last_need_w = 0;      // longest list (entries, padded) the last build reported
+    uint32_t dense_budget = 0;     // dense_guard: longest list (entries) the memory budget admits
     uint32_t K = 4, adapt = 1;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
@@ -866,22 +867,28 @@ static unsigned pick_tile_cap(unsigned need)
 }
 
 // A build that meets a dense state -- the spline-refined start of the pipeline is a globule in which some beads have 1 500
-// neighbours inside the default list radius -- must not size every row of the handle for it: the list width is narrowed so that
-// the longest list, which grows with the cube of the radius, comes down to ~384 entries (at least a skin of 0.15 x cutoff; such
-// states move fast, their rebuild interval is a few steps at any width).  class_skin returns to the default width once the
-// longest list, scaled back to it, is short again.  Not with a caller-chosen skin.
+// neighbours inside the default list radius -- sizes every row of the handle for its longest list (rows are uniform).  While
+// that fits a sixteenth of the device memory at two bytes per entry nothing is done (128 x 30 000 beads x 1 520 entries = 11.7 GB
+// of 288); beyond it the list width is narrowed so that the longest list, which grows with the cube of the radius, fits (at
+// least a skin of 0.15 x cutoff), and class_skin returns to the width it left once the longest list, scaled back, fits again.
+// Not with a caller-chosen skin.
 static void dense_guard(gd_system *s, unsigned need_w)
 {
     if (s->skin_fixed || need_w <= 512u || !(s->rv > 0)) return;
     const double cut = pair_cutoff(s);
     if (!(cut > 0)) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
+    const double w_budget = std::min((double)GD_TILED_MAX_W, (double)(total_b / 16) / (2.0 * (double)s->R * (double)s->Np));
+    if ((double)need_w <= w_budget) return;
+    s->dense_budget = (uint32_t)std::max(64.0, w_budget);
     const double sc = s->rv / cut - s->skin;                       // bead-scale part of the radius the build used
-    const double r_new = s->rv * std::cbrt(384.0 / (double)need_w);
+    const double r_new = s->rv * std::cbrt(0.9 * w_budget / (double)need_w);
     const double skin_new = std::max(0.15, r_new / cut - sc);
     if (skin_new < s->skin - 1e-9) {
         if (!(s->skin_dense_from > 0)) s->skin_dense_from = s->skin;
         s->skin = skin_new; s->skin_next = 0; s->K = std::max(1u, std::min(s->K, 4u)); s->a2_ema = 0;
-        s->W = 448;      // (the narrowed list is predicted at 384 entries; a miss is one more exactly sized build)
+        s->W = std::max(64u, s->dense_budget & ~7u);      // (the narrowed list is predicted at 0.9 of the budget; a miss is one more exactly sized build)
         if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state (longest list %u): skin %.3f\n", need_w, skin_new);
     }
 }
@@ -1050,6 +1057,7 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
 {
     auto &t = s->tuner;
     if (!t.enabled || s->sw_n) return;
+    if (s->skin_dense_from > 0 || s->skin_next > 0) return;      // a dense transient at its narrow width (dense_guard): the selection starts once it has passed
     if (rolled_back) { t.settle = std::max(t.settle, 1); t.acc_ms = 0; t.acc_steps = 0; t.measured = 0; return; }
     if (!full_interval || !(s->a2_ema > 0)) return;
     if (t.done) {      // conditions drift (a relaxation, a growing bead scale): look again, around the width in use, once the
@@ -1133,8 +1141,9 @@ static void class_skin(gd_system *s, const gd_run_desc *run)
         // again; the timing-based selection, when enabled, starts from there
         const unsigned need_w = s->last_need_w;
         const double cut = pair_cutoff(s), sc0 = s->rv / cut - s->skin, ratio = (sc0 + s->skin_dense_from) / (sc0 + s->skin);
-        if (need_w > 0 && (double)need_w * ratio * ratio * ratio <= 256.0 && !(s->skin_next > 0)) {
+        if (need_w > 0 && (double)need_w * ratio * ratio * ratio <= 0.8 * (double)s->dense_budget && !(s->skin_next > 0)) {
             s->skin_next = s->skin_dense_from; s->skin_dense_from = 0;
+            { const bool on = s->tuner.enabled; s->tuner = gd_system::SkinTuner{}; s->tuner.enabled = on; }      // (a fresh selection from the default width)
             if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state has passed (longest list %u): skin %.3f at the next build\n", need_w, s->skin_next);
         }
         return;

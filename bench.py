@@ -157,6 +157,20 @@ def _cached_traffic(n_beads, replicas, list_entries_per_bead):
     return None
 
 
+def _cached_replay(n_beads, replicas):
+    """The replay measurement of k_step (tools/replay.py -> profiles/r*_replay.json: its memory pattern alone, its arithmetic alone,
+    on this workload's relaxed state), while it describes the kernel being timed (same kernel source hash)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_replay.json")), reverse=True):
+        try:
+            rj = json.load(open(path))
+            if rj.get("workload") == {"n_beads": n_beads, "replicas_per_gpu": replicas} and rj.get("kernel_source_sha") == _kernel_source_sha():
+                return dict(rj, source="profiles/" + os.path.basename(path))
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
 def other_workloads(g, wl, hip, dev_index, budget_steps=600):
     """The measurements BASELINE.md / SURVEY 8d list beside the headline, each after its own (short) relaxation, same
     clock as the headline (wall time of gd_run): ms per step, bead-steps/s, rollbacks.  Reported under config.other_workloads."""
@@ -395,6 +409,12 @@ def main():
                          "whole_step_frac_at_survey_list": 204.0 * N * R * a.steps / el / 1e9 / HBM_PEAK_GBS,
                          "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},
         }
+        rp = _cached_replay(N, R)
+        if rp:
+            # what actually bounds k_step: VALU issue.  Its arithmetic alone (operands resident, same grid and LDS class) takes t_alu,
+            # its memory pattern alone t_mem; the product kernel overlaps the two almost completely (profiles/README.md)
+            out["roofline"]["issue_bound"] = {"t_alu_us": rp["t_alu_us"], "t_mem_us": rp["t_mem_us"], "t_kstep_fresh_list_us": rp["t_kstep_us"],
+                                              "overlap": rp["overlap"], "kstep_over_alu_bound": rp["t_alu_us"] / rp["t_kstep_us"], "source": rp["source"]}
         if not a.no_cpu_baseline and world == 1:
             out["checked"] = check_against_oracle(g, wl, sys_, N, R // 2)
             out["cpu_baseline"], farm_cpu = cpu_baseline(g, wl, sys_.positions()[0], N)
