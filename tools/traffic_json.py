@@ -3,10 +3,11 @@ HBM bytes per k_step launch = 2 x FETCH_SIZE + WRITE_SIZE (KB = 1024 B; FETCH_SI
 half the bytes of 16-byte-per-lane streaming reads).  usage: traffic_json.py <tag> [dir]"""
 import hashlib, json, os, re, sys
 tag = sys.argv[1]; d = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
-# usage: traffic_json.py <tag> [dir [kernel [n_beads replicas [suffix]]]]
+# usage: traffic_json.py <tag> [dir [kernel [n_beads replicas [suffix [launches_per_step]]]]]  (bytes and time are per STEP)
 kern = sys.argv[3] if len(sys.argv) > 3 else "k_step<0, false, true, 1, true, false>"
 n_beads, replicas = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (30000, 128)
 suffix = sys.argv[6] if len(sys.argv) > 6 else ""
+per_step = int(sys.argv[7]) if len(sys.argv) > 7 else 1      # launches of this kernel per step (a step split by tile class is two)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sha = hashlib.sha256()
 for f in ("gdyn_kernels.hip", "gdyn_types.h"):
@@ -22,11 +23,12 @@ avg_us = None
 for line in open(f"{d}/{tag}{suffix}_bench_kernel_stats.txt"):
     if kern in line: avg_us = float(re.search(r"avg_us\s+([\d.]+)", line).group(1))
 fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
-b = (2 * fetch + write) * 1024
+b = (2 * fetch + write) * 1024 * per_step
+if avg_us is not None: avg_us *= per_step
 out = {"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no tracing domains: tools/pmc.sh via tools/profile_round.sh) of "
                    "`bench.py --load-state <relaxed state> --warmup 200 --steps 200 --no-cpu-baseline --no-extra`, kernel " + kern + ", mean per dispatch over "
                    f"{vals['FETCH_SIZE'][1]} dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B-per-lane streaming reads); KB = 1024 B",
-       "workload": {"n_beads": n_beads, "replicas_per_gpu": replicas},
+       "workload": {"n_beads": n_beads, "replicas_per_gpu": replicas}, "launches_per_step": per_step,
        "kernel_source_sha": sha.hexdigest()[:16], "list_entries_per_bead": bench.get("list_entries_per_bead", bench.get("config", {}).get("list_entries_per_bead")),
        "list_radius": bench.get("list_radius", bench.get("config", {}).get("list_radius")),
        "k_step": {"fetch_size_kb": fetch, "write_size_kb": write, "corrected_bytes_per_launch": b, "rocprof_avg_launch_us": avg_us,
