@@ -132,6 +132,7 @@ struct gd_system {
     double skin_next = 0;          // width the next list build moves to (the list in use serves out its interval; 0: none pending)
     double skin_dense_from = 0;    // > 0: the width was narrowed because a build met a dense state (dense_guard); the width to return to
     uint32_t last_need_w = 0;      // longest list (entries, padded) the last build reported
+    uint32_t ncell_seen = 0;       // largest cell grid of the last build that reported one (sizes k_scan's launch)
     uint32_t dense_budget = 0;     // dense_guard: longest list (entries) the memory budget admits
     uint32_t K = 4, adapt = 1;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
@@ -815,6 +816,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.periodic = s->box_kind == GD_BOX_PERIODIC;
     for (int k = 0; k < 3; k++) { b.box[k] = (float)s->box[k]; b.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
     b.rv = rv; b.ncell_cap = s->ncell_cap; b.dmax = s->dmax.p;
+    b.scan_segments = std::min((s->ncell_seen + s->ncell_seen / 4 + 8191u) / 8192u, (s->ncell_cap + 8191u) / 8192u);      // (0 before the first build: one block per replica)
     {   // near-class radius: the (look-ahead) cutoff the list radius was derived from, plus a share of the skin
         const float cutb = rv - (float)(pair_cutoff(s) * s->skin);
         b.rn = (cutb > 0.f && cutb < rv) ? cutb + (float)s->near_frac * (rv - cutb) : rv;
@@ -904,6 +906,11 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     }
     if (need_t > 0 && need_t < (1u << 20)) s->last_need_t = need_t;
     if (need_w > 0) s->last_need_w = need_w;
+    {
+        unsigned nc = 0;
+        for (uint32_t r = 0; r < s->R; r++) nc = std::max(nc, f[r * GD_NFLAGS + GD_FLAG_NCELL]);
+        if (nc > 0) s->ncell_seen = nc;
+    }
     if (!tover && !over && s->list_tiled && need_t > 0) {
         // size the LDS tile to what the builds actually need (more resident blocks per CU)
         // LDS capacity is a step function of the tile size: k_step keeps 3 / 2 / 1 blocks (6 / 4 / 2 waves per SIMD)

@@ -39,7 +39,8 @@ enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
 
 // flags[r*GD_NFLAGS + k]
 enum { GD_FLAG_VIOLATION = 0, GD_FLAG_OVERFLOW = 1, GD_FLAG_MAXDISP2 = 2, GD_FLAG_NEED_W = 3, GD_FLAG_TILE_OVERFLOW = 4,
-       GD_FLAG_NEED_TILE = 5, GD_FLAG_TAINT = 6, GD_NFLAGS = 8 };
+       GD_FLAG_NEED_TILE = 5, GD_FLAG_TAINT = 6, GD_FLAG_NCELL = 7, GD_NFLAGS = 8 };
+// GD_FLAG_NCELL: cells of the replica's grid at the last build (sizes the scan's launch at the next one)
 // GD_FLAG_TAINT: set by a list build that starts after an overflow was flagged in the same chunk -- the steps since ran on
 // incomplete lists, the positions are no basis for sizing anything: such a build reports no needs (the chunk is rolled back)
 
@@ -219,6 +220,7 @@ struct BuildParams {
     float rn;                           // near-class radius of tiled lists (cutoff < rn <= rv)
     unsigned *dmax;                     // [R] largest squared displacement since the build (float bits)
     unsigned ncell_cap;
+    unsigned scan_segments;             // blocks per replica of k_scan (the last one walks whatever is left)
     const float4 *pos_in;               // current order
     float4 *pos_out;                    // new (sorted) order
     float4 *xb;
