@@ -881,8 +881,10 @@ static void dense_guard(gd_system *s, unsigned need_w)
     if (!(cut > 0)) return;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
-    const double w_budget = std::min((double)GD_TILED_MAX_W, (double)(total_b / 16) / (2.0 * (double)s->R * (double)s->Np));
-    if ((double)need_w <= w_budget) return;
+    // rows of the width the build asked for: two bytes per entry while a tiled row can hold them, four on the generic path
+    const double rows = (double)s->R * (double)s->Np, budget_b = (double)(total_b / 16);
+    if ((double)need_w * (need_w <= GD_TILED_MAX_W ? 2.0 : 4.0) * rows <= budget_b) return;      // (fits: also when only the tiled record is too small for it)
+    const double w_budget = std::min((double)GD_TILED_MAX_W, budget_b / (2.0 * rows));
     s->dense_budget = (uint32_t)std::max(64.0, w_budget);
     const double sc = s->rv / cut - s->skin;                       // bead-scale part of the radius the build used
     const double r_new = s->rv * std::cbrt(0.9 * w_budget / (double)need_w);

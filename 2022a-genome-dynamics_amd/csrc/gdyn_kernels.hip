@@ -1682,14 +1682,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             const unsigned sd = self_l - j0;
                             if (sd < n) m &= ~(1u << (n - 1u - sd));
                             mn &= m; m ^= mn;                                 // near class, far class
+                            // (lowest set bit first: find-first-bit, then clear it with m & (m - 1) -- three instructions less per entry than
+                            // isolating the highest bit; the order of a bead's entries is immaterial)
                             while (mn) {
-                                const unsigned bit = 31u - (unsigned)__clz(mn);
-                                mn ^= 1u << bit;
+                                const unsigned bit = (unsigned)__builtin_ctz(mn);
+                                mn &= mn - 1u;
                                 push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
                             }
                             while (m) {
-                                const unsigned bit = 31u - (unsigned)__clz(m);
-                                m ^= 1u << bit;
+                                const unsigned bit = (unsigned)__builtin_ctz(m);
+                                m &= m - 1u;
                                 push_far(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
                             }
                         }
@@ -1742,15 +1744,17 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             if (sd < n) m &= ~(1u << (n - 1u - sd));
                             mn &= m; m ^= mn;                                // near class, far class
                             GD_FSTAMP(3);     // distance tests
-                            while (mn) {                                     // ascending candidate order
+                            // (lowest set bit first: find-first-bit, then clear it with m & (m - 1) -- three instructions less per entry than
+                            // isolating the highest bit; the order of a bead's entries is immaterial)
+                            while (mn) {
                                 GD_FCOUNT(9);
-                                const unsigned bit = 31u - (unsigned)__clz(mn);
-                                mn ^= 1u << bit;
+                                const unsigned bit = (unsigned)__builtin_ctz(mn);
+                                mn &= mn - 1u;
                                 push(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
                             }
                             while (m) {
-                                const unsigned bit = 31u - (unsigned)__clz(m);
-                                m ^= 1u << bit;
+                                const unsigned bit = (unsigned)__builtin_ctz(m);
+                                m &= m - 1u;
                                 push_far(S16 ? (j0 + (n - 1u - bit)) << 4 : j0 + (n - 1u - bit));
                             }
                             GD_FSTAMP(4);     // appends
@@ -1791,9 +1795,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = S16 ? idx << 4 : idx; }
             const unsigned needA = (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u), needB = (cntB + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
             const unsigned needw = needA + needB;
-            // the tiled record counts the chunks of EACH class in 5 bits: a class beyond 31 chunks does not fit it even when the
-            // row is wide enough for the sum -- flagged like a row overflow, with a need beyond every tiled width (the host
-            // then builds generic lists until the dense transient has passed)
+            // the tiled record counts the near entries in fours (11 bits: 1 016 entries) and the far chunks in 6 bits (504 entries): a
+            // class beyond that does not fit it even when the row is wide enough for the sum -- flagged like a row overflow, with a
+            // need beyond every tiled width (the host then builds generic lists until the dense transient has passed)
             const bool class_over = TILED && (needA > GD_TILED_MAX_NEAR || needB > GD_TILED_MAX_FAR);
             if ((needw > p.W || (TILED && needw > GD_TILED_MAX_W) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
                 p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;

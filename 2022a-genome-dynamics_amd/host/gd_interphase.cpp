@@ -61,7 +61,9 @@ private:
     std::vector<std::string> _notes;
 };
 timing_table g_timing;
-#define TIMED(name) timing_table::scope timed_scope_##__LINE__{g_timing, name}
+#define GD_CONCAT2(a, b) a##b
+#define GD_CONCAT(a, b) GD_CONCAT2(a, b)      // (two levels: __LINE__ expands before the paste)
+#define TIMED(name) timing_table::scope GD_CONCAT(timed_scope_, __LINE__){g_timing, name}
 
 // Time-integrated contact maps (simulation_interphase/contact_map.cc:26-91) live on the device, one per replica (gd_contacts_*):
 // an update is one pair search over all replicas plus one insert launch, and only a dump moves rows to the host.
