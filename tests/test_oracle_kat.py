@@ -460,3 +460,34 @@ def test_wall_distance_matches_the_reference_geometry_module(oracle):
             assert r * a[i] / (a[i] + 1e-6) == pytest.approx(ref[i], rel=1e-7, abs=1e-10), (k, i)
             checked += 1
         assert checked >= 5 and (~inside).sum() >= 50
+
+
+def test_compensated_update_arithmetic_emulated():
+    """The arithmetic of k_step's compensated position update (gdyn_kernels.hip, integrate section), emulated in numpy float32:
+    t = lo + e; x' = x + t; b = x' - x; lo' = (x - (x' - b)) + (t - b) -- Knuth's two-sum, exact in round-to-nearest -- against the
+    fp64 sum of the same increments, in the regime of simulation_fine_sampling (|x| of 3 ... 8, increments of 0.1 ... 4 ulp).  The
+    plain fp32 update `x += e` on the same increments loses per cent of the displacement and leaves coordinates where they were."""
+    rng = np.random.default_rng(1)
+    n, steps = 20000, 300
+    x0 = (rng.uniform(3.0, 8.0, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    inc = (rng.normal(0.0, 9.0, n) * 1e-7).astype(np.float32)            # mu F dt per step, F ~ 9: constant over the run
+    x, lo, xp = x0.copy(), np.zeros(n, np.float32), x0.copy()
+    exact = x0.astype(np.float64)
+    for _ in range(steps):
+        e = inc
+        t = lo + e
+        xn = x + t
+        b = xn - x
+        lo = (x - (xn - b)) + (t - b)
+        x = xn
+        xp = xp + e
+        exact = exact + e.astype(np.float64)
+    d_exact = exact - x0
+    d_comp = (x.astype(np.float64) + lo.astype(np.float64)) - x0
+    d_plain = xp.astype(np.float64) - x0
+    med = np.median(np.abs(d_exact))
+    assert np.abs(d_comp - d_exact).max() <= 1e-6 * med                       # exact to the rounding of lo + e
+    assert np.all(np.abs(lo) <= np.spacing(np.abs(x)) * 0.5000001)            # the pair stays normalised
+    assert np.median(np.abs(d_plain - d_exact)) > 5e-3 * med                  # the plain update: per cent of the displacement ...
+    moving = np.abs(d_exact) > 1e-6
+    assert (d_plain[moving] == 0).mean() > 0.01                               # ... and coordinates that never move
