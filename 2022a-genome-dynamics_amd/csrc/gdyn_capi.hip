@@ -962,11 +962,15 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
 }
 
 // Synchronous build used outside gd_run: grows the list width until nothing overflows.
-static int build_now(gd_system *s, float rv, bool with_list, bool allow_tiled = true)
+static int build_now(gd_system *s, float rv, bool with_list, bool allow_tiled = true, float rv_min = 0.f)
 {
+    const double skin0 = s->skin;
     for (int attempt = 0; attempt < 10; attempt++) {
         GDCHK(clear_flags(s));
-        GDCHK(enqueue_build(s, rv, with_list, allow_tiled));
+        // (a retry after the dense guard has narrowed the width builds at the narrowed radius -- not below what the caller needs
+        // the list to cover, rv_min: a pair search at a contact distance beyond the force cutoff)
+        const float rv_try = std::max(rv_min, rv - (float)(pair_cutoff(s) * (skin0 - s->skin)));
+        GDCHK(enqueue_build(s, rv_try, with_list, allow_tiled));
         std::vector<unsigned> f;
         GDCHK(read_flags(s, f));
         if (!handle_overflow(s, f)) {
@@ -1483,7 +1487,7 @@ static int search_device(gd_system *s, uint32_t r0, uint32_t nrep, double dcut, 
             take_pending_skin(s);
             const float rv_force = with_list ? list_radius(s, s->last_dt > 0 ? &ahead : nullptr, s->K) : 0.f;
             const float rv_search = (float)(dcut * (1.0 + 1e-6));
-            GDCHK(build_now(s, std::max(rv_force, rv_search), true));
+            GDCHK(build_now(s, std::max(rv_force, rv_search), true, true, rv_search));
             s->list_valid = true; s->search_list = rv_search > rv_force;
         }
         const double lim = 0.5 * ((double)s->rv - dcut);

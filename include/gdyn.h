@@ -332,8 +332,11 @@ int gd_contacts_clear(gd_system *sys, uint32_t replica);
 
 typedef struct {
     double   skin;              /* Verlet skin as a fraction of the NOMINAL pair cutoff: list radius = cutoff * (bead_scale + skin),
-                                   i.e. an absolute width that a scaled-down cutoff does not shrink; 0 keeps the current
-                                   value (default 0.75) */
+                                   i.e. an absolute width that a scaled-down cutoff does not shrink.  A value > 0 pins the width.
+                                   0 keeps the library's own choice: 0.75, widened to 0.9 while the largest LDS tile of the wider
+                                   list fits the three-block class (a rule on the state: tile sizes are cell counts; see
+                                   DESIGN.md section 4), narrowed while a dense state's longest list would not fit the
+                                   memory budget */
     uint32_t rebuild_interval;  /* initial steps between list builds; 0 = auto */
     uint32_t adapt_interval;    /* 1 = adapt interval from measured displacements */
     uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
