@@ -4,7 +4,7 @@
 out=$1; root=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 [ -f /tmp/state.npy ] || python3 $root/bench.py --save-state /tmp/state.npy > /dev/null 2>&1
-for lib in libgdyn_dev.so libgdyn_abl40.so libgdyn_abl41.so; do
+for lib in ${REPLAY_LIBS:-libgdyn_dev.so libgdyn_abl40.so libgdyn_abl41.so}; do
   rm -rf /tmp/rp_$lib
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d /tmp/rp_$lib -- python3 $root/tools/replay_worker.py $lib /tmp/state.npy 60 > /tmp/rp_$lib.log 2>&1
   python3 - "$lib" /tmp/rp_$lib >> $out <<'PY'
