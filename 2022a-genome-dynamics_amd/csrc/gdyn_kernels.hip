@@ -151,15 +151,32 @@ __device__ __forceinline__ double wave_sum_d(double v)
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-__device__ __forceinline__ float wave_max_f(float v)      // v >= 0
+// (v >= 0, not NaN: the maximum is taken on the bit patterns as unsigned integers, which order like the floats.  fmaxf on the DPP
+// operand compiled to a zero move, the DPP move, a canonicalising self-maximum and the maximum -- four instructions per step on a
+// kernel that is bound by VALU issue; the integer form fuses into one v_max_u32 with the DPP modifier)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp0_u(unsigned v)
 {
-    v = fmaxf(v, dpp0<0x111, 0xf>(v));
-    v = fmaxf(v, dpp0<0x112, 0xf>(v));
-    v = fmaxf(v, dpp0<0x114, 0xf>(v));
-    v = fmaxf(v, dpp0<0x118, 0xf>(v));
-    v = fmaxf(v, dpp0<0x142, 0xa>(v));
-    v = fmaxf(v, dpp0<0x143, 0xc>(v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_max_f(float vf)      // vf >= 0
+{
+    unsigned v = __float_as_uint(vf);
+    v = max(v, dpp0_u<0x111, 0xf>(v));
+    v = max(v, dpp0_u<0x112, 0xf>(v));
+    v = max(v, dpp0_u<0x114, 0xf>(v));
+    v = max(v, dpp0_u<0x118, 0xf>(v));
+    v = max(v, dpp0_u<0x142, 0xa>(v));
+    v = max(v, dpp0_u<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
+}
+// max without the canonicalising self-maximum the compiler puts in front of fmaxf on a value loaded from memory (neither operand is
+// a signalling NaN here: a bond record's lower clamp, an elongation)
+__device__ __forceinline__ float fmax_plain(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // u2^(n/2) for even n in {0,2,4,6,10}
@@ -737,7 +754,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
                             // harmonic / spring / semispring in one form: elongation x = r - l clamped from below
                             // (r2 = 0 -- a padding entry, coincident beads -- gives x = -l and a finite fr on d = 0: zero force, like the guarded form)
                             const float inv_d = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));     // hardware rsq, 1 ulp
-                            const float x = fmaxf(fmaf(r2, inv_d, -l), tb[u].y);
+                            const float x = fmax_plain(fmaf(r2, inv_d, -l), tb[u].y);
                             float fr = -K * x * inv_d, e = 0.f;
                             if (MODE == GD_MODE_ENERGY) e = 0.5f * K * x * x;
                             if (p.has_softcore_bonds && s_bt[ty[u]].kind == POT_SOFTCORE) {      // (rare bond form; uniform test first)
