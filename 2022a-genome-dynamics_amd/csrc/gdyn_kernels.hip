@@ -433,7 +433,12 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             // tile staging by LDS-DMA (global_load_lds_dwordx4): each wave copies 64 consecutive slots =
             // 1 KiB straight into LDS (destination = wave-uniform base + lane*16), no register hop; the
             // __syncthreads() below waits for the outstanding DMAs (vmcnt) before the tile is read.
-            const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)(wid * 64u));
+            // Stepping: wave 0 stages the bond table only and leaves the tile to the other seven waves (pieces of 64 slots, stride
+            // 448) -- it carries the block's context work in front of the barrier, and without its share of the DMA issue (and of
+            // the DMAs in front of its context load) it no longer is the wave the others wait for.
+            constexpr bool W0_FREE = MODE == GD_MODE_STEP;
+            const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)((W0_FREE ? (wid == 0 ? 0x100000u : wid - 1u) : wid) * 64u));
+            constexpr unsigned DMA_STRIDE = W0_FREE ? GD_BLOCK - 64u : GD_BLOCK;
             if (wid == 0 && lane < 2 * GD_MAX_BOND_TYPES)       // the bond-type table: 32 B per type, 16 B per lane (the buffer always holds the full table)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)p.btab + lane),
                                                  (__attribute__((address_space(3))) void *)s_bt, 16, 0, 0);
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             for (int k = 0; k < GD_TILE_RANGES; base += tlen[k], k++) {
 #endif
                 const unsigned len = tlen[k], st = tst[k];
-                for (unsigned q0 = wq; q0 < len; q0 += GD_BLOCK) {      // (wave-uniform loop: scalar control, one compare per lane)
+                for (unsigned q0 = wq; q0 < len; q0 += DMA_STRIDE) {      // (wave-uniform loop: scalar control, one compare per lane)
                     if (q0 + lane < len)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(rpos + st + q0) + lane * 16u),
                                                          (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
