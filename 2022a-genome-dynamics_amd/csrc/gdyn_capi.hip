@@ -1200,6 +1200,12 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     GDCHK(apply_pending(s));
     s->state_serial++;
     if (run->timestep != s->last_dt || run->temperature != s->last_kT) { s->a2_ema = 0; s->last_dt = run->timestep; s->last_kT = run->temperature; }   // another regime: measure afresh
+    // The wall or the scales start (or stop) moving with this run -- a relaxation is followed by the production phase: the
+    // displacement statistics the interval was adapted on are those of the other regime, and the first intervals of the new one used
+    // to end in a rolled-back chunk every few runs (bench.py: flags 0 for the relaxation, wall dynamics + scale updates after it).
+    // A fifth off the interval until complete intervals of the new regime have been measured.
+    if (s->adapt && s->K > 4 && ((run->flags ^ s->last_flags) & (GD_RUN_WALL_DYNAMICS | GD_RUN_UPDATE_SCALES)) != 0 && s->rebuilds > 0)
+        s->K -= s->K / 5;
     s->last_flags = run->flags;
     const bool with_list = pair_cutoff(s) > 0;
     const size_t RN = (size_t)s->R * s->N;

@@ -341,6 +341,9 @@ def main():
     # chance), time-boxed; reported beside `value`, never instead of it
     K_now = max(int(sys_.context(0).rebuild_interval), 1)
     n_ss = min(max(40 * K_now, 400), 4000)
+    # (ten intervals untimed first: with --warmup 5 the wall dynamics were switched on 25 steps ago, and the interval adaptation has
+    # not seen a complete interval of this phase yet -- the window below is the STEADY state)
+    sys_.run(10 * K_now, dt, kT, seed=seed, flags=flags)
     farm.barrier(); torch.cuda.synchronize()
     t_ss = time.perf_counter()
     sys_.run(n_ss, dt, kT, seed=seed, flags=flags)
