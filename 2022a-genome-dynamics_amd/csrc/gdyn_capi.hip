@@ -134,6 +134,8 @@ struct gd_system {
     uint32_t last_need_w = 0;      // longest list (entries, padded) the last build reported
     uint32_t ncell_seen = 0;       // largest cell grid of the last build that reported one (sizes k_scan's launch)
     uint32_t dense_budget = 0;     // dense_guard: longest list (entries) the memory budget admits
+    bool all_near = false;         // single-class lists (near radius = list radius): a build met a far class beyond the tiled record's
+                                   // 504 entries; two classes again once the longest list is below that
     uint32_t K = 4, adapt = 1;
     uint32_t K_bad = 0, K_bad_ttl = 0;   // interval that violated the skin recently: stay below it for a while
     uint32_t steps_since_build = 0;
@@ -819,7 +821,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.scan_segments = std::min((s->ncell_seen + s->ncell_seen / 4 + 8191u) / 8192u, (s->ncell_cap + 8191u) / 8192u);      // (0 before the first build: one block per replica)
     {   // near-class radius: the (look-ahead) cutoff the list radius was derived from, plus a share of the skin
         const float cutb = rv - (float)(pair_cutoff(s) * s->skin);
-        b.rn = (cutb > 0.f && cutb < rv) ? cutb + (float)s->near_frac * (rv - cutb) : rv;
+        b.rn = (cutb > 0.f && cutb < rv && !s->all_near) ? cutb + (float)s->near_frac * (rv - cutb) : rv;
     }
     b.pos_in = s->pos[s->pcur].p; b.pos_out = s->pos[s->pcur ^ 1].p; b.xb = s->xb.p;
     b.orig_in = s->orig[s->ocur].p; b.orig_out = s->orig[s->ocur ^ 1].p; b.slot_of = s->slot_of.p;
@@ -870,8 +872,9 @@ static unsigned pick_tile_cap(unsigned need)
 
 // A build that meets a dense state -- the spline-refined start of the pipeline is a globule in which some beads have 1 500
 // neighbours inside the default list radius -- sizes every row of the handle for its longest list (rows are uniform).  While
-// that fits a sixteenth of the device memory at two bytes per entry nothing is done (128 x 30 000 beads x 1 520 entries = 11.7 GB
-// of 288); beyond it the list width is narrowed so that the longest list, which grows with the cube of the radius, fits (at
+// that fits a sixteenth of the device memory at two bytes per entry nothing is done (128 x 30 000 beads x 2 340 entries = 18 GB
+// of 288; a quarter of the memory -- rows of 8 688 entries, interval 3 instead of 1 -- was measured on the 128-file pipeline:
+// the same 20 s of gd_run, the work of such a state is its pairs, not its builds); beyond it the list width is narrowed so that the longest list, which grows with the cube of the radius, fits (at
 // least a skin of 0.15 x cutoff), and class_skin returns to the width it left once the longest list, scaled back, fits again.
 // Not with a caller-chosen skin.
 static void dense_guard(gd_system *s, unsigned need_w)
@@ -901,9 +904,10 @@ static void dense_guard(gd_system *s, unsigned need_w)
 // fall back to the generic path. Returns true when a build has to be redone.
 static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
 {
-    unsigned need_w = 0, need_t = 0; bool over = false, tover = false;
+    unsigned need_w = 0, need_t = 0; bool over = false, tover = false, class_over = false;
     for (uint32_t r = 0; r < s->R; r++) {
         over |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] != 0; need_w = std::max(need_w, f[r * GD_NFLAGS + GD_FLAG_NEED_W]);
+        class_over |= (f[r * GD_NFLAGS + GD_FLAG_OVERFLOW] & 2u) != 0;
         tover |= f[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] != 0; need_t = std::max(need_t, f[r * GD_NFLAGS + GD_FLAG_NEED_TILE]);
     }
     if (need_t > 0 && need_t < (1u << 20)) s->last_need_t = need_t;
@@ -941,9 +945,16 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         unsigned w = need_w + need_w / 16 + 8;
         if (need_w <= GD_TILED_MAX_W) w = std::min(w, GD_TILED_MAX_W);
         s->W = std::max(w, s->W + 8);
+        if (class_over) {
+            // a class beyond its field of the tiled record: single-class lists while that is the far class; a near class beyond
+            // 8 184 entries is beyond tiled rows
+            if (!s->all_near && need_w <= GD_TILED_MAX_NEAR) s->all_near = true;
+            else s->W = std::max(s->W, GD_TILED_MAX_W + 8u);
+        }
         dense_guard(s, need_w);
     }
     else if (!tover && need_w > 0) {
+        if (s->all_near && need_w <= GD_TILED_MAX_FAR) s->all_near = false;      // (no far class can overflow its field any more; from the next build)
         // the longest list is reported by every build: give the row width back when a dense transient has passed
         const unsigned want_w = std::max(64u, (need_w + need_w / 4 + 16 + GD_UNROLL - 1) & ~(GD_UNROLL - 1));
         if (2 * want_w <= s->W) s->W = want_w;       // (takes effect at the next build; the list in use keeps list_W)

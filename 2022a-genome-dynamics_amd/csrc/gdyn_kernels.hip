@@ -1817,13 +1817,13 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             if (TILED) { unsigned idx = 0; if (to_local(slot, idx)) self = S16 ? idx << 4 : idx; }
             const unsigned needA = (cnt + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u), needB = (cntB + GD_UNROLL - 1u) & ~(GD_UNROLL - 1u);
             const unsigned needw = needA + needB;
-            // the tiled record counts the near entries in fours (11 bits: 1 016 entries) and the far chunks in 6 bits (504 entries): a
-            // class beyond that does not fit it even when the row is wide enough for the sum -- flagged like a row overflow, with a
-            // need beyond every tiled width (the host then builds generic lists until the dense transient has passed)
+            // the tiled record counts the near entries in fours (11 bits: 8 184 entries) and the far chunks in 6 bits (504 entries): a
+            // class beyond that does not fit it even when the row is wide enough for the sum -- flagged like a row overflow, bit 1 on
+            // top (the host then builds single-class lists, or generic ones beyond 8 184 entries, until the dense transient has passed)
             const bool class_over = TILED && (needA > GD_TILED_MAX_NEAR || needB > GD_TILED_MAX_FAR);
             if ((needw > p.W || (TILED && needw > GD_TILED_MAX_W) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
-                p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] = 1u;
-                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], class_over ? max(needw, GD_TILED_MAX_W + 1u) : needw);
+                atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], class_over ? 3u : 1u);
+                atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], needw);
             }
             listlen = min(found, p.W);
             nAq = min((cnt + 3u) / 4u, GD_TILED_MAX_NEAR / 4u);            // near entries in fours (the record's count; chunks are still written whole)

@@ -27,8 +27,10 @@
 #define GD_XCDS 8
 #define GD_REC_NOBEAD 0xffffffffu          // tiled per-thread record: rec_mo.y of a thread without a bead
 // tiled per-thread record (rec_mo): x = bond degree | point-source mask << 8 | block-local slot << 12 | near entries / 4 << 21 (11 bits),
-// y = bead id (26 bits, like a bond partner) | far chunks << 26 (6 bits).  The classes are capped where the fields and a sane row end:
-#define GD_TILED_MAX_NEAR 1016u            // near entries (127 chunks of 8)
+// y = bead id (26 bits, like a bond partner) | far chunks << 26 (6 bits).  The classes are capped where the fields end.  A bead whose far
+// class does not fit (the spline-refined start of the pipeline: some beads have 4 000 neighbours inside the default list radius) is
+// flagged (GD_FLAG_OVERFLOW bit 1) and the host builds single-class lists -- everything near -- until the dense state has passed.
+#define GD_TILED_MAX_NEAR 8184u            // near entries (1 023 chunks of 8; 2 046 fours in the record's 11 bits)
 #define GD_TILED_MAX_FAR 504u              // far entries (63 chunks)
 #define GD_TILED_MAX_W (GD_TILED_MAX_NEAR + GD_TILED_MAX_FAR)
 #define GD_REC_ID_MASK 0x03ffffffu         // bead id field of rec_mo.y; all ones = no bead

@@ -769,13 +769,14 @@ def test_energy_after_a_deferred_run_uses_the_verified_resident_list(hip, oracle
     assert s.context().rebuilds == b1 + 1
 
 
-@pytest.mark.parametrize("n_core,width,path_expected", [(360, 400, 2), (1100, 1200, 1)])
+@pytest.mark.parametrize("n_core,width,path_expected", [(360, 400, 2), (1100, 1200, 2)])
 def test_dense_cluster_within_and_beyond_the_tiled_record(hip, oracle, n_core, width, path_expected):
     """A ball of radius 0.1 in which every pair is inside the near radius + a dilute background, tiled path requested.
     360 beads: 359 near entries per bead, more than the 248 a list class held before the record's count fields were widened
     (11 bits of near entries in fours, 6 bits of far chunks) -- stays on the tiled path and matches the oracle.
-    1 100 beads: beyond the 1 016 near entries the record counts even though the row is wide enough -- the build must flag it
-    and leave the tiled path, not clamp the chunk count (forces and contact pairs would silently miss neighbours)."""
+    1 100 beads: beyond the 1 016 near entries rounds 2-3 capped the class at -- the field holds 8 184: tiled as well.  (A near
+    class beyond THAT needs a tile of more than the 8 192 entries the LDS holds: such a state leaves the tiled path through the
+    tile overflow, test_dense_cluster_falls_back_to_generic_path; the far class beyond its 504 entries: the next test.)"""
     rng = np.random.default_rng(11)
     n = n_core + 840
     v = rng.normal(size=(n_core, 3))
@@ -797,6 +798,40 @@ def test_dense_cluster_within_and_beyond_the_tiled_record(hip, oracle, n_core, w
         assert abs(np.linalg.norm(x[i] - x[j]) - 0.3) < 1e-6
     assert len(Po) > n_core * (n_core - 1) // 2 - 10
     assert path == path_expected
+
+
+def test_far_class_beyond_the_tiled_record_builds_single_class_lists(hip, oracle):
+    """Two balls of 600 beads (radius 0.01) 0.49 apart: every bead holds the other ball in its FAR class (near radius 0.446, list
+    radius 0.525 at the pinned width) -- 600 entries where the record's far field counts 504.  The build flags it (bit 1 of the
+    overflow flag) and the handle builds single-class lists: tiled path kept, forces / energy / pair set as the oracle's; after
+    the balls have been pulled apart the next builds return to two classes and still agree."""
+    rng = np.random.default_rng(5)
+    nb, n = 600, 2 * 600 + 800
+    def ball(c):
+        v = rng.normal(size=(nb, 3))
+        return c + 0.01 * v / np.linalg.norm(v, axis=1)[:, None] * rng.random((nb, 1)) ** (1 / 3)
+    x = np.concatenate([ball(np.array([0.0, 0.0, 0.0])), ball(np.array([0.49, 0.0, 0.0])),
+                        (rng.random((n - 2 * nb, 3)) - 0.5) * 6.0 + np.array([0.0, 0.0, 5.0])]).astype(np.float32).astype(np.float64)
+    def make(lib):
+        s = g.System(lib, n, 1)
+        s.set_bead_params(a=(np.arange(n) % 2).astype(float), b=((np.arange(n) + 1) % 2).astype(float))
+        s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
+        if lib is hip:
+            s.set_tuning(kernel_path=2, skin=0.75, near_fraction=0.65)
+        return s
+    sh, so = make(hip), make(oracle)
+    for xs in (x, np.concatenate([x[:nb], x[nb:2 * nb] + np.array([2.0, 0.0, 0.0]), x[2 * nb:]])):
+        res = []
+        for s in (sh, so):
+            s.set_positions(xs)
+            res.append((s.forces(), s.energy(), {tuple(p) for p in s.search_pairs(0.3)}))
+        (Fh, Eh, Ph), (Fo, Eo, Po) = res
+        assert np.abs(Fh - Fo).max() <= FORCE_RTOL * np.abs(Fo).max()
+        assert abs(Eh[0] - Eo[0]) <= 1e-5 * abs(Eo[0])
+        for i, j in Ph ^ Po:
+            assert abs(np.linalg.norm(xs[i] - xs[j]) - 0.3) < 1e-6
+        assert len(Po) >= 2 * (nb * (nb - 1) // 2)
+        assert sh.context().list_path == 2
 
 
 # ---------------------------------------------------------------- trajectories at scale, at the benchmark's cadence

@@ -56,7 +56,9 @@ for r in range(R):
     t_prep["spindle"] = t_prep.get("spindle", 0) + run(os.path.join(HOST, "gd_spindle"), f)[0]
     t_prep["refine"] = t_prep.get("refine", 0) + run(sys.executable, os.path.join(HOST, "gd_refine.py"), f)[0]
     files.append(f)
-t_inter, res = run(os.path.join(HOST, "gd_interphase"), "--timing", *os.environ.get("GD_INTERPHASE_ARGS", "").split(), *files)
+# (GD_INTERPHASE_WRAP="rocprofv3 --kernel-trace --stats -d <dir> --": the program under the profiler, directly after the "--")
+t_inter, res = run(*os.environ.get("GD_INTERPHASE_WRAP", "").split(), os.path.join(HOST, "gd_interphase"), "--timing",
+                   *os.environ.get("GD_INTERPHASE_ARGS", "").split(), *files)
 log = [ln for ln in res.stderr.splitlines() if ln.startswith("[")]
 total_steps = cfg["relaxation_steps"] + steps
 size = sum(os.path.getsize(f) for f in files)
