@@ -150,7 +150,10 @@ struct gd_system {
     DevBuf<unsigned> badj_o; DevBuf<int4> chain_o; DevBuf<BondType> btab;
     // device: per slot
     DevBuf<float4> pos[2], xb, fout, snap;
-    DevBuf<unsigned> orig[2], slot_of, cell_id, rank, cell_cnt, cell_start, nbr, meta, badj, flags, cell_s;
+    DevBuf<unsigned> orig[2], slot_of, rank, cell_cnt, cell_start, nbr, meta, badj, flags;
+    DevBuf<float> bbox_enc, bbox_w;      // box of the last build's positions (two halves: read / written), k_scatter's per-wave partials
+    int bbox_cur = 0;              // half of bbox_enc the next build reads (the other one is accumulated by it)
+    bool bbox_valid = false;       // open boxes: bbox_enc[bbox_cur] holds the bounding box of the positions the last build sorted
     DevBuf<unsigned short> nbr16; DevBuf<TileDesc> tiles;
     DevBuf<float4> rec_x0; DevBuf<uint2> rec_mo; DevBuf<unsigned char> len_prev;
     DevBuf<float> bbox;
@@ -247,14 +250,14 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
         ok = ok && s->pos[k].resize(RNp) == hipSuccess && s->orig[k].resize(RNp) == hipSuccess && s->ctx[k].resize(s->R) == hipSuccess &&
              s->react_part[k].resize((size_t)s->R * s->nblk) == hipSuccess;
     }
-    ok = ok && s->xb.resize(RNp) == hipSuccess && s->slot_of.resize(RN) == hipSuccess && s->cell_id.resize(RNp) == hipSuccess &&
+    ok = ok && s->xb.resize(RNp) == hipSuccess && s->slot_of.resize(RN) == hipSuccess && s->bbox_enc.resize((size_t)2 * s->R * 6) == hipSuccess && s->bbox_w.resize((size_t)s->R * s->nblk * (GD_BLOCK / 64) * 6) == hipSuccess &&
          s->rank.resize(RNp) == hipSuccess && s->cell_cnt.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess &&
          s->cell_start.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess && s->meta.resize(RNp) == hipSuccess &&
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->lcount_d.resize(s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
-         s->cell_s.resize(RNp) == hipSuccess && s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
+         s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess &&
          s->lo.resize(RN) == hipSuccess;
     s->lo_valid = ok;      // (positions and residuals all zero)
@@ -314,7 +317,7 @@ extern "C" int gd_set_positions(gd_system *s, const double *xyz)
     s->lo_valid = true;
     gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->list_valid = false; s->state_serial++; s->w_packed = false;
+    s->list_valid = false; s->state_serial++; s->w_packed = false; s->bbox_valid = false;
     return GD_OK;
 }
 
@@ -818,6 +821,8 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.periodic = s->box_kind == GD_BOX_PERIODIC;
     for (int k = 0; k < 3; k++) { b.box[k] = (float)s->box[k]; b.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
     b.rv = rv; b.ncell_cap = s->ncell_cap; b.dmax = s->dmax.p;
+    b.kx = b.periodic ? 1 : 2;
+    if (const char *e = dev_env("GDYN_KX")) b.kx = b.periodic ? 1 : std::max(1, atoi(e));      // (experiments: cells per list radius in x)
     b.scan_segments = std::min((s->ncell_seen + s->ncell_seen / 4 + 8191u) / 8192u, (s->ncell_cap + 8191u) / 8192u);      // (0 before the first build: one block per replica)
     {   // near-class radius: the (look-ahead) cutoff the list radius was derived from, plus a share of the skin
         const float cutb = rv - (float)(pair_cutoff(s) * s->skin);
@@ -825,18 +830,21 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     }
     b.pos_in = s->pos[s->pcur].p; b.pos_out = s->pos[s->pcur ^ 1].p; b.xb = s->xb.p;
     b.orig_in = s->orig[s->ocur].p; b.orig_out = s->orig[s->ocur ^ 1].p; b.slot_of = s->slot_of.p;
-    b.cell_id = s->cell_id.p; b.rank = s->rank.p; b.cell_cnt = s->cell_cnt.p; b.cell_start = s->cell_start.p;
+    b.rank = s->rank.p; b.cell_cnt = s->cell_cnt.p; b.cell_start = s->cell_start.p;
     b.bbox = s->bbox.p; b.grid = s->grid.p;
+    b.bbox_cur = s->bbox_enc.p + (size_t)s->bbox_cur * s->R * 6; b.bbox_next = s->bbox_enc.p + (size_t)(s->bbox_cur ^ 1) * s->R * 6;
+    b.warm = (b.periodic || s->bbox_valid) ? 1 : 0; b.bbox_w = s->bbox_w.p;
     b.ab_o = s->ab_o.p; b.mob_o = s->mob_o.p; b.bendE_o = s->bendE_o.p; b.psmask_o = s->psmask_o.p;
     b.badj_o = s->badj_o.p; b.bdeg_o = s->bdeg_o.p; b.chain_o = s->has_bend ? s->chain_o.p : nullptr; b.WB = s->WB;
     b.ab = s->ab.p; b.mob = s->mobs.p; b.bendE = s->bendE.p; b.badj = s->badj.p; b.has_bend = s->has_bend ? 1 : 0;
     b.mob_is_uniform = s->mob_uniform >= 0.f ? 1 : 0;
     b.chain = s->chain.p; b.nbr = (with_list && !tiled) ? s->nbr.p : nullptr; b.nbr16 = tiled ? s->nbr16.p : nullptr;
-    b.meta = s->meta.p; b.rec_x0 = s->rec_x0.p; b.rec_mo = s->rec_mo.p; b.len_prev = s->len_prev.p; b.W = s->W; b.tiles = s->tiles.p; b.cell_s = s->cell_s.p; b.tiled = tiled ? 1 : 0;
+    b.meta = s->meta.p; b.rec_x0 = s->rec_x0.p; b.rec_mo = s->rec_mo.p; b.len_prev = s->len_prev.p; b.W = s->W; b.tiles = s->tiles.p; b.tiled = tiled ? 1 : 0;
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.w_valid = (s->packed_ab && s->w_packed) ? 1 : 0;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
     gd_launch_build(b, s->stream);
+    s->bbox_cur ^= 1; s->bbox_valid = tiled;      // (the box of the positions this build sorted, reduced by k_tiles: the next build's grid)
     s->list_tiled = tiled; s->list_tile_cap = s->tile_cap;
     s->w_packed = s->packed_ab;
     s->pcur ^= 1; s->ocur ^= 1;
@@ -900,6 +908,12 @@ static void dense_guard(gd_system *s, unsigned need_w)
     }
 }
 
+// (class_skin, below: the handle runs at the wider of its two list widths)
+static bool class_skin_wide(const gd_system *s)
+{
+    return !s->skin_fixed && s->adapt && !s->tuner.enabled && !(s->skin_dense_from > 0) && !s->sw_n && s->skin >= 0.9 - 1e-9 && s->skin <= 0.9 + 1e-9;
+}
+
 // React to list-width / tile-capacity overflow flags: widen the list, enlarge the LDS tile or
 // fall back to the generic path. Returns true when a build has to be redone.
 static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
@@ -925,6 +939,9 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // keeps the larger class for a while, so the margin for the smaller class can be thin)
         unsigned want = pick_tile_cap(need_t + 24);
         if (want < s->tile_cap && s->tile_hold > 0) { s->tile_hold--; want = s->tile_cap; }
+        // at the width class_skin selected the tiles are about to leave the three-block class: class_skin (called after this) takes
+        // the narrower list back at the next build, where they fit it -- no detour through the two-block class
+        if (want > 3312u && s->tile_cap <= 3312u && class_skin_wide(s)) want = s->tile_cap;
         if (want != s->tile_cap && want <= 8192u) {
             if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] tile capacity %u -> %u (largest tile %u)\n", s->tile_cap, want, need_t);
             s->tile_cap = want;
@@ -1155,7 +1172,8 @@ static bool want_compensated(const gd_system *s, const gd_run_desc *run)
 // the largest tile stays inside the three-block LDS class (3 312 entries); one class up every block loses a third of its occupancy
 // (S-genome-62k at 0.9: -15 %).  So: the handle starts at 0.75 and moves to 0.9 once the largest tile of the builds, scaled to the
 // wider list (the halo part of a tile grows with the square of the list radius), has fitted the class for three accepted
-// chunks in a row; it moves back when a build at 0.9 leaves the class, and waits 64 chunks before it looks again.  The rule reads
+// chunks in a row; it moves back when the largest tile of a build at 0.9 comes within 24 entries of the class (the next build is
+// already at 0.75: no build in the two-block class in between), and waits 64 chunks before it looks again.  The rule reads
 // the state only (tile sizes are cell counts), never a clock: the same state selects the same width.  Not with a caller-chosen skin
 // (gd_tuning.skin), not while the timing-based selection (gd_tuning.auto_skin) is on.
 static void class_skin(gd_system *s, const gd_run_desc *run)
@@ -1188,7 +1206,7 @@ static void class_skin(gd_system *s, const gd_run_desc *run)
         const double own = 3.0 * GD_BLOCK, est = own + std::max(0.0, (double)s->last_need_t - own) * ratio * ratio + 24.0;
         if (est <= 3312.0 - 24.0 && s->list_tile_cap <= 3312u) { if (++s->skin_streak >= 3) move_to(hi); }
         else s->skin_streak = 0;
-    } else if (s->skin <= hi + 1e-9 && s->list_tile_cap > 3312u) { move_to(lo); s->skin_hold = 64; }
+    } else if (s->skin <= hi + 1e-9 && (s->list_tile_cap > 3312u || s->last_need_t + 24u > 3312u)) { move_to(lo); s->skin_hold = 64; }
 }
 
 extern "C" int gd_apply_callback(gd_system *s)
@@ -1276,7 +1294,10 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         };
         size_t nev = 0;
         float step_ms = 0, build_ms = 0;
-        std::vector<std::pair<size_t, int>> spans;   // event index, kind (0 step, 1 build)
+        // Spans of step launches and of builds share their boundary events: the end of one is the start of the next (an event in the
+        // stream costs the device ~5 us between two kernels -- kernel trace of one 30 000-bead replica: 0.3 us between two steps,
+        // 10-12 us across the two events that used to separate a build from the steps on either side)
+        std::vector<std::pair<size_t, int>> spans;   // index of the span's end event (its start: the event before it), kind (0 step, 1 build)
         hipEvent_t ev_begin = get_event(s, nev++);
         HIPCHK(hipEventRecord(ev_begin, s->stream));
         int64_t k = 0;
@@ -1287,17 +1308,15 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         while (k < chunk) {
             if (!s->list_valid || s->steps_since_build >= s->K) {
                 take_pending_skin(s);
-                hipEvent_t e0 = get_event(s, nev++), e1 = get_event(s, nev++);
-                HIPCHK(hipEventRecord(e0, s->stream));
+                hipEvent_t e1 = get_event(s, nev++);
                 GDCHK(enqueue_build(s, list_radius(s, run, (uint32_t)(k + s->K)), with_list));
                 s->search_list = false;
                 HIPCHK(hipEventRecord(e1, s->stream));
-                spans.push_back({nev - 2, 1});
+                spans.push_back({nev - 1, 1});
                 s->list_valid = true;
             }
             const int64_t n = std::min<int64_t>((int64_t)s->K - s->steps_since_build, chunk - k);
-            hipEvent_t e0 = get_event(s, nev++), e1 = get_event(s, nev++);
-            HIPCHK(hipEventRecord(e0, s->stream));
+            hipEvent_t e1 = get_event(s, nev++);
             for (int64_t q = 0; q < n; q++) {
                 fill_common(s, p);
                 p.dt_d = run->timestep; p.dt = (float)run->timestep; p.kT = (float)run->temperature; p.seed = run->seed;
@@ -1314,7 +1333,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
                 s->pcur ^= 1; s->ccur ^= 1;
             }
             HIPCHK(hipEventRecord(e1, s->stream));
-            spans.push_back({nev - 2, 0});
+            spans.push_back({nev - 1, 0});
             s->timing.step_launches += (uint64_t)n;
             s->steps_since_build += (uint32_t)n;
             k += n;
@@ -1359,6 +1378,8 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         if (violated || over) {
             // roll the chunk back: restore bead-order positions + context, shorten the interval / widen the list
             s->rollbacks++;
+            if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] rollback %llu: %s, K %u, skin %.3f, chunk of %lld steps at step %lld\n", (unsigned long long)s->rollbacks,
+                                               over ? "overflow" : "skin violation", s->K, s->skin, (long long)chunk, (long long)s->hctx[0].step);
             HIPCHK(hipMemcpy2DAsync(s->pos[s->pcur].p, (size_t)s->Np * sizeof(float4), s->snap.p, (size_t)s->N * sizeof(float4),
                                     (size_t)s->N * sizeof(float4), s->R, hipMemcpyDeviceToDevice, s->stream));
             gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
@@ -1366,6 +1387,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             s->hctx = snap_ctx; s->ctx_dirty = true; s->w_packed = snap_w_packed;
             GDCHK(upload_ctx(s));
             s->list_valid = false;
+            s->bbox_valid = false;      // (the box the abandoned builds recorded may be that of positions stepped on incomplete lists)
             if (violated && !over) {
                 if (s->K == 1) {
                     if (s->skin > 8) return fail(GD_ESTATE, "gd_run: Verlet skin cannot cover one step (timestep too large?)");
@@ -1387,7 +1409,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         }
         float ms = 0;
         for (auto &sp : spans) {
-            HIPCHK(hipEventElapsedTime(&ms, s->events[sp.first], s->events[sp.first + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, s->events[sp.first - 1], s->events[sp.first]));
             (sp.second ? build_ms : step_ms) += ms;
         }
         HIPCHK(hipEventElapsedTime(&ms, ev_begin, ev_end));

@@ -1181,12 +1181,48 @@ __global__ __launch_bounds__(GD_BLOCK) void k_bbox(const BuildParams p)
 // one block per replica: its first wave reduces the bounding box and chooses the cell grid (every wave computes the same grid: the
 // inputs are uniform), all GD_GRIDP_THREADS threads clear the cell counters (148 877 cells per replica on the 1 kb model: one wave
 // took 38 us over them)
+// the cell grid of one replica on the box (lo, lo + e): cells >= rv (1/kx of that in x, open boxes); the cell size grows until the cell
+// count fits the allocation
+__device__ __forceinline__ GridP grid_on(const BuildParams &p, float lo0, float lo1, float lo2, float e0, float e1, float e2)
+{
+    const int extra = p.periodic ? 0 : 1;
+    if (!p.periodic) {
+        if (!(e0 > 0.f)) e0 = p.rv;
+        if (!(e1 > 0.f)) e1 = p.rv;
+        if (!(e2 > 0.f)) e2 = p.rv;
+    }
+    float cs = p.rv;
+    const int kx = p.periodic ? 1 : max(p.kx, 1);
+    int n0 = 1, n1 = 1, n2 = 1;
+    for (int it = 0; it < 64; it++) {
+        n0 = kx * max((int)floorf(e0 / cs) + extra, 1);
+        n1 = max((int)floorf(e1 / cs) + extra, 1);
+        n2 = max((int)floorf(e2 / cs) + extra, 1);
+        if ((float)n0 * (float)n1 * (float)n2 <= (float)p.ncell_cap) break;
+        cs *= 1.26f;
+    }
+    GridP g;
+    g.org[0] = lo0; g.org[1] = lo1; g.org[2] = lo2;
+    if (p.periodic) { g.inv[0] = (float)n0 / e0; g.inv[1] = (float)n1 / e1; g.inv[2] = (float)n2 / e2; }
+    else { g.inv[0] = (float)kx / cs; g.inv[1] = 1.0f / cs; g.inv[2] = 1.0f / cs; }
+    g.nc[0] = n0; g.nc[1] = n1; g.nc[2] = n2;
+    g.ncell = n0 * n1 * n2;
+    return g;
+}
+// warm builds: the grid from the box (periodic) or from the bounding box the build before recorded -- every block of k_bin / k_scatter
+// computes the same grid from the same six words
+__device__ __forceinline__ GridP grid_warm(const BuildParams &p, unsigned r)
+{
+    if (p.periodic) return grid_on(p, 0.f, 0.f, 0.f, p.box[0], p.box[1], p.box[2]);
+    const float *b = p.bbox_cur + r * 6;
+    return grid_on(p, b[0], b[1], b[2], b[3] - b[0], b[4] - b[1], b[5] - b[2]);
+}
+
 #define GD_GRIDP_THREADS 256
-__global__ __launch_bounds__(GD_GRIDP_THREADS) void k_gridp(const BuildParams p)
+__global__ __launch_bounds__(GD_GRIDP_THREADS) void k_gridp(const BuildParams p)      // cold builds (open boxes): after k_bbox
 {
     const unsigned r = blockIdx.x, lane = threadIdx.x & 63u;
     float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, e0 = p.box[0], e1 = p.box[1], e2 = p.box[2];
-    const int extra = p.periodic ? 0 : 1;
     if (!p.periodic) {
         float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, h0 = -INFINITY, h1 = -INFINITY, h2 = -INFINITY;
         for (unsigned b = lane; b < p.nblk; b += 64) {
@@ -1200,38 +1236,11 @@ __global__ __launch_bounds__(GD_GRIDP_THREADS) void k_gridp(const BuildParams p)
         }
         lo0 = l0; lo1 = l1; lo2 = l2;
         e0 = h0 - l0; e1 = h1 - l1; e2 = h2 - l2;
-        if (!(e0 > 0.f)) e0 = p.rv;
-        if (!(e1 > 0.f)) e1 = p.rv;
-        if (!(e2 > 0.f)) e2 = p.rv;
     }
-    // cells >= rv; grow the cell size until the cell count fits the allocation
-    float cs = p.rv;
-    int n0 = 1, n1 = 1, n2 = 1;
-    for (int it = 0; it < 64; it++) {
-        n0 = max((int)floorf(e0 / cs) + extra, 1);
-        n1 = max((int)floorf(e1 / cs) + extra, 1);
-        n2 = max((int)floorf(e2 / cs) + extra, 1);
-        if ((float)n0 * (float)n1 * (float)n2 <= (float)p.ncell_cap) break;
-        cs *= 1.26f;
-    }
-    // the cell counters of this replica's grid start from zero (one wave clears them; replaces a memset of the whole
-    // allocation), and so do the per-build replica counters
-    {
-        unsigned *cc = p.cell_cnt + (size_t)r * (p.ncell_cap + 1);
-        const unsigned ncell = (unsigned)(n0 * n1 * n2);
-        for (unsigned c = threadIdx.x; c <= ncell && c <= p.ncell_cap; c += GD_GRIDP_THREADS) cc[c] = 0u;
-    }
+    const GridP g = grid_on(p, lo0, lo1, lo2, e0, e1, e2);
     if (threadIdx.x == 0) {
-        p.lcount[r] = 0ull;
-        p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
-        if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
-        GridP *g = p.grid + r;
-        g->org[0] = lo0; g->org[1] = lo1; g->org[2] = lo2;
-        if (p.periodic) { g->inv[0] = (float)n0 / e0; g->inv[1] = (float)n1 / e1; g->inv[2] = (float)n2 / e2; }
-        else { g->inv[0] = 1.0f / cs; g->inv[1] = 1.0f / cs; g->inv[2] = 1.0f / cs; }
-        g->nc[0] = n0; g->nc[1] = n1; g->nc[2] = n2;
-        g->ncell = n0 * n1 * n2;
-        p.flags[r * GD_NFLAGS + GD_FLAG_NCELL] = (unsigned)(n0 * n1 * n2);
+        p.grid[r] = g;
+        p.flags[r * GD_NFLAGS + GD_FLAG_NCELL] = (unsigned)g.ncell;
     }
 }
 
@@ -1251,7 +1260,9 @@ __device__ __forceinline__ void cell_coords(const GridP &g, const float4 x, cons
     }
 }
 
-template <bool PERIODIC>
+// WARM: every block lays the replica's grid itself (grid_warm) and the replica's first block records it for the kernels that follow;
+// cold builds read the grid k_gridp wrote.
+template <bool PERIODIC, bool WARM>
 __global__ __launch_bounds__(GD_BLOCK) void k_bin(const BuildParams p)
 {
     const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
@@ -1259,8 +1270,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_bin(const BuildParams p)
     const bool valid = slot < p.N;
     const size_t g = (size_t)r * p.Np + slot;
     unsigned c = 0xffffffffu;
+    const GridP gp = WARM ? grid_warm(p, r) : p.grid[r];
+    if (WARM && blk == 0 && threadIdx.x == 0) { p.grid[r] = gp; p.flags[r * GD_NFLAGS + GD_FLAG_NCELL] = (unsigned)gp.ncell; }
     if (valid) {
-        const GridP gp = p.grid[r];
         int cx, cy, cz;
         cell_coords<PERIODIC>(gp, p.pos_in[g], p.inv_box, cx, cy, cz);
         c = (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx);
@@ -1277,10 +1289,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_bin(const BuildParams p)
     unsigned base = 0;
     if (head && valid) base = atomicAdd(&p.cell_cnt[(size_t)r * (p.ncell_cap + 1) + c], next_head - lane);
     base = __shfl(base, head_lane, 64);
-    if (valid) {
-        p.cell_id[g] = c;
-        p.rank[g] = base + (lane - head_lane);
-    }
+    if (valid) p.rank[g] = base + (lane - head_lane);      // (k_scatter finds the cell again from the position: 4 bytes per bead less each way)
 }
 
 // exclusive scan of the cell counts of one replica; the counts go through LDS in coalesced tiles so that each thread can scan a
@@ -1295,6 +1304,11 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
     const unsigned r = blockIdx.x, tid = threadIdx.x;
     const unsigned n = (unsigned)p.grid[r].ncell;
     unsigned t0 = blockIdx.y * GD_SCAN_TILE;
+    if (blockIdx.y == 0 && tid == 1023) {      // the per-build words of the replica start over (the last wave: off the path of the scan)
+        p.lcount[r] = 0ull;
+        p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
+        if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
+    }
     if (t0 >= n) return;
     const bool last_block = blockIdx.y + 1 == gridDim.y;      // walks every tile that is left (the launch is sized from the previous build)
     const unsigned *cnt = p.cell_cnt + (size_t)r * (p.ncell_cap + 1);
@@ -1338,37 +1352,26 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
     }
 }
 
-__global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
-{
-    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
-    const unsigned slot = blk * GD_BLOCK + threadIdx.x;
-    if (slot >= p.N) return;
-    const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
-    const unsigned c = p.cell_id[g];
-    const unsigned ns = p.cell_start[(size_t)r * (p.ncell_cap + 1) + c] + p.rank[g];
-    const unsigned o = p.orig_in[g];
-    float4 x = p.pos_in[g];
-    // (a,b) ride in pos.w and every kernel carries w along: only positions that came from the host (w = 0) need the per-bead
-    // gather again
-    float2 ab = make_float2(0.f, 0.f);
-    if (!p.packed_ab || !p.w_valid) ab = p.ab_o[o];
-    if (p.packed_ab && !p.w_valid) x.w = pack_ab(ab);
-    const size_t gn = rbase + ns;
-    p.pos_out[gn] = x;
-    if (!p.tiled) p.xb[gn] = x;      // build positions by slot: the generic path's skin check (the tiled path keeps them per thread, rec_x0)
-    p.orig_out[gn] = o;
-    p.cell_s[gn] = c;
-    p.slot_of[(size_t)r * p.N + o] = ns;
-    if (!p.packed_ab) p.ab[gn] = ab;
-    if (!p.mob_is_uniform) p.mob[gn] = p.mob_o[o];
-    if (p.has_bend) p.bendE[gn] = p.bendE_o[o];
-}
-
-// One thread per block of slots: the (up to 9) slot ranges of its LDS tile. A block covers the contiguous
+// The (up to 9) slot ranges of the LDS tile of one block of slots. A block covers the contiguous
 // cell range [c0,c1] (cells are numbered x-fastest); the cells adjacent to any of them lie, for each
-// (dz,dy), in the linear range [c0+off-1, c1+off+1] with off = (dz*ny + dy)*nx (a superset).
-__global__ void k_tiles(const BuildParams p)
+// (dz,dy), in the linear range [c0+off-kx, c1+off+kx] with off = (dz*ny + dy)*nx (a superset; kx cells in x are one list radius).
+// (One thread per block of slots.  Run by one thread of the k_scatter block (r, blk) instead -- its index arrays live in scratch memory,
+// and a kernel that needs scratch runs few waves at a time -- k_scatter took 914 us instead of 60.)
+__global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
 {
+    const unsigned nb_tiles = (p.R * p.nblk + 63u) / 64u;
+    if (blockIdx.x >= nb_tiles) {      // open boxes, one more wave per replica: the bounding box of the sorted positions from k_scatter's partials
+        const unsigned r = blockIdx.x - nb_tiles, nw = p.nblk * (GD_BLOCK / 64);
+        float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, h0 = -INFINITY, h1 = -INFINITY, h2 = -INFINITY;
+        for (unsigned i = threadIdx.x; i < nw; i += 64) {
+            const float *b = p.bbox_w + ((size_t)r * nw + i) * 6;
+            l0 = fminf(l0, b[0]); l1 = fminf(l1, b[1]); l2 = fminf(l2, b[2]); h0 = fmaxf(h0, b[3]); h1 = fmaxf(h1, b[4]); h2 = fmaxf(h2, b[5]);
+        }
+        l0 = wave_minmax<false>(l0); l1 = wave_minmax<false>(l1); l2 = wave_minmax<false>(l2);
+        h0 = wave_minmax<true>(h0); h1 = wave_minmax<true>(h1); h2 = wave_minmax<true>(h2);
+        if (threadIdx.x < 6) p.bbox_next[r * 6 + threadIdx.x] = threadIdx.x == 0 ? l0 : threadIdx.x == 1 ? l1 : threadIdx.x == 2 ? l2 : threadIdx.x == 3 ? h0 : threadIdx.x == 4 ? h1 : h2;
+        return;
+    }
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.R * p.nblk) return;
     const unsigned r = t / p.nblk, blk = t % p.nblk;
@@ -1377,7 +1380,15 @@ __global__ void k_tiles(const BuildParams p)
     const GridP gp = p.grid[r];
     const unsigned *__restrict__ cs = p.cell_start + (size_t)r * (p.ncell_cap + 1);
     const unsigned first = blk * GD_BLOCK, last = min(first + GD_BLOCK, p.N) - 1;
-    const int c0 = (int)p.cell_s[rbase + first], c1 = (int)p.cell_s[rbase + last];
+    // cells of the block's first and last slot: found again from the sorted positions (the sort keeps no cell index per slot)
+    int c0, c1;
+    {
+        const float4 xa = p.pos_out[rbase + first], xz = p.pos_out[rbase + last];
+        int ax, ay, az, zx, zy, zz;
+        if (p.periodic) { cell_coords<true>(gp, xa, p.inv_box, ax, ay, az); cell_coords<true>(gp, xz, p.inv_box, zx, zy, zz); }
+        else { cell_coords<false>(gp, xa, p.inv_box, ax, ay, az); cell_coords<false>(gp, xz, p.inv_box, zx, zy, zz); }
+        c0 = (az * gp.nc[1] + ay) * gp.nc[0] + ax; c1 = (zz * gp.nc[1] + zy) * gp.nc[0] + zx;
+    }
     TileDesc td;
     if (p.periodic) {
         // Periodic boxes: the tile is made of WHOLE rows of cells (a row = fixed (z,y), all x; the x-neighbours of the
@@ -1447,7 +1458,7 @@ __global__ void k_tiles(const BuildParams p)
     for (int k = 0; k < GD_TILE_RANGES; k++) {
         const int dz = k / 3 - 1, dy = k % 3 - 1;
         const int off = (dz * gp.nc[1] + dy) * gp.nc[0];
-        const int lo = max(c0 + off - 1, 0), hi = min(c1 + off + 1, gp.ncell - 1);
+        const int lo = max(c0 + off - p.kx, 0), hi = min(c1 + off + p.kx, gp.ncell - 1);      // (kx cells in x are one list radius)
         klo[k] = lo; kin[k] = -1;
         if (lo > hi) continue;
         if (nm > 0 && lo <= mhi[nm - 1] + 1) mhi[nm - 1] = max(mhi[nm - 1], hi);
@@ -1482,6 +1493,45 @@ __global__ void k_tiles(const BuildParams p)
 
     if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
     p.tiles[t] = td;
+}
+
+// Counting-sort scatter into the new slot order (+ the static per-slot data); open boxes: every wave also records the bounding box of
+// the positions it moves, for the next build's grid (the kernel is memory-bound: the reductions are free).
+template <bool PERIODIC>
+__global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
+{
+    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool valid = slot < p.N;
+    const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
+    const GridP gp = p.grid[r];
+    float4 x = valid ? p.pos_in[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!PERIODIC) {
+        const float l0 = wave_minmax<false>(valid ? x.x : INFINITY), l1 = wave_minmax<false>(valid ? x.y : INFINITY), l2 = wave_minmax<false>(valid ? x.z : INFINITY);
+        const float h0 = wave_minmax<true>(valid ? x.x : -INFINITY), h1 = wave_minmax<true>(valid ? x.y : -INFINITY), h2 = wave_minmax<true>(valid ? x.z : -INFINITY);
+        // (one partial per wave, plain stores: atomics on the replica's six words -- 470 waves each -- made this kernel 5 x slower)
+        if (lane < 6) p.bbox_w[((size_t)r * p.nblk * (GD_BLOCK / 64) + blk * (GD_BLOCK / 64) + (threadIdx.x >> 6)) * 6 + lane] =
+            lane == 0 ? l0 : lane == 1 ? l1 : lane == 2 ? l2 : lane == 3 ? h0 : lane == 4 ? h1 : h2;
+    }
+    if (!valid) return;
+    int cx, cy, cz;
+    cell_coords<PERIODIC>(gp, x, p.inv_box, cx, cy, cz);       // as k_bin found it
+    const unsigned c = (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx);
+    const unsigned ns = p.cell_start[(size_t)r * (p.ncell_cap + 1) + c] + p.rank[g];
+    const unsigned o = p.orig_in[g];
+    // (a,b) ride in pos.w and every kernel carries w along: only positions that came from the host (w = 0) need the per-bead
+    // gather again
+    float2 ab = make_float2(0.f, 0.f);
+    if (!p.packed_ab || !p.w_valid) ab = p.ab_o[o];
+    if (p.packed_ab && !p.w_valid) x.w = pack_ab(ab);
+    const size_t gn = rbase + ns;
+    p.pos_out[gn] = x;
+    if (!p.tiled) p.xb[gn] = x;      // build positions by slot: the generic path's skin check (the tiled path keeps them per thread, rec_x0)
+    p.orig_out[gn] = o;
+    p.slot_of[(size_t)r * p.N + o] = ns;
+    if (!p.packed_ab) p.ab[gn] = ab;
+    if (!p.mob_is_uniform) p.mob[gn] = p.mob_o[o];
+    if (p.has_bend) p.bendE[gn] = p.bendE_o[o];
 }
 
 // Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
@@ -1605,12 +1655,21 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             p.chain[g] = make_int4(conv(c.x), conv(c.y), conv(c.z), conv(c.w));
         }
         GD_FSTAMP(1);     // bond / chain re-map
+        if (!(p.nbr || p.nbr16)) {      // (a sort without lists: the counter of the bead's cell still goes back to zero, see below)
+            const GridP gp = p.grid[r];
+            int cx, cy, cz;
+            cell_coords<PERIODIC>(gp, rpos[slot], p.inv_box, cx, cy, cz);
+            p.cell_cnt[(size_t)r * (p.ncell_cap + 1) + (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx)] = 0u;
+        }
         if (p.nbr || p.nbr16) {
             const GridP gp = p.grid[r];
             const float4 xi = rpos[slot];
             const unsigned *__restrict__ cs = p.cell_start + (size_t)r * (p.ncell_cap + 1);
             int cx, cy, cz;
             cell_coords<PERIODIC>(gp, xi, p.inv_box, cx, cy, cz);
+            // the counters k_bin counted into go back to zero for the next build: every bead clears its own cell's (the lanes of a
+            // wave sit in a handful of neighbouring cells: a line or two per store instruction); nothing reads them after k_scan
+            p.cell_cnt[(size_t)r * (p.ncell_cap + 1) + (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx)] = 0u;
             const float rv2 = p.rv * p.rv;
             // Tiled lists are kept in TWO classes by the distance at the build: "near" entries (closer than rn) in the chunks
             // from the front of the bead's row, "far" entries (rn <= d < rv) in the chunks from its back.  A pair that is not
@@ -1721,7 +1780,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                     if (k2 & 1) flush();
                 }
             } else if (TILED) {
-                const unsigned x_lo = (unsigned)max(cx - 1, 0), x_hi = (unsigned)min(cx + 1, gp.nc[0] - 1);
+                const unsigned x_lo = (unsigned)max(cx - p.kx, 0), x_hi = (unsigned)min(cx + p.kx, gp.nc[0] - 1);
                 // all 18 row-bound loads are issued before the first sweep (memory-level parallelism)
                 unsigned rb[GD_TILE_RANGES], re[GD_TILE_RANGES];
 #pragma unroll
@@ -1786,9 +1845,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 }
             } else {
                 // distinct neighbour cells per dimension (small periodic grids alias)
-                const int nz = PERIODIC ? min(3, gp.nc[2]) : 3, ny = PERIODIC ? min(3, gp.nc[1]) : 3, nx = PERIODIC ? min(3, gp.nc[0]) : 3;
+                const int nz = PERIODIC ? min(3, gp.nc[2]) : 3, ny = PERIODIC ? min(3, gp.nc[1]) : 3, nx = PERIODIC ? min(3, gp.nc[0]) : 2 * p.kx + 1;
                 const int z0 = (PERIODIC && gp.nc[2] < 3) ? 0 : cz - 1, y0 = (PERIODIC && gp.nc[1] < 3) ? 0 : cy - 1,
-                          x0 = (PERIODIC && gp.nc[0] < 3) ? 0 : cx - 1;
+                          x0 = PERIODIC ? (gp.nc[0] < 3 ? 0 : cx - 1) : cx - p.kx;
                 for (int iz = 0; iz < nz; iz++) {
                     int zz = z0 + iz;
                     if (PERIODIC) zz = (zz + gp.nc[2]) % gp.nc[2]; else if (zz < 0 || zz >= gp.nc[2]) continue;
@@ -1867,12 +1926,20 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 void gd_launch_build(const BuildParams &p, hipStream_t st)
 {
     const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk);
-    if (!p.periodic) hipLaunchKernelGGL(k_bbox, dim3(p.R * ((p.nblk + 3u) / 4u)), block, 0, st, p);
-    hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(GD_GRIDP_THREADS), 0, st, p);
-    if (p.periodic) hipLaunchKernelGGL(k_bin<true>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(k_bin<false>, grid, block, 0, st, p);
+    // five launches: count + rank (the grid laid by every block itself) | scan | scatter (+ the box of the next build's grid) | tile
+    // descriptors | fill (+ the cell counters back to zero).  An open box without a bounding box from the build before (the first build of a handle, positions set by
+    // the caller): k_bbox and k_gridp in front.
+    if (p.periodic) hipLaunchKernelGGL((k_bin<true, true>), grid, block, 0, st, p);
+    else if (p.warm) hipLaunchKernelGGL((k_bin<false, true>), grid, block, 0, st, p);
+    else {
+        hipLaunchKernelGGL(k_bbox, dim3(p.R * ((p.nblk + 3u) / 4u)), block, 0, st, p);
+        hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(GD_GRIDP_THREADS), 0, st, p);
+        hipLaunchKernelGGL((k_bin<false, false>), grid, block, 0, st, p);
+    }
     hipLaunchKernelGGL(k_scan, dim3(p.R, std::max(1u, p.scan_segments)), dim3(1024), 0, st, p);
-    hipLaunchKernelGGL(k_scatter, grid, block, 0, st, p);
+    if (p.periodic) hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p);
+    if (p.tiled) hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64 + (p.periodic ? 0u : p.R)), dim3(64), 0, st, p);
     if (p.tiled) {
         static bool once = false;
         if (!once) {
@@ -1882,7 +1949,6 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
-        hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
         const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
         if (p.periodic) {
             if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p);

@@ -223,15 +223,25 @@ struct BuildParams {
     unsigned *dmax;                     // [R] largest squared displacement since the build (float bits)
     unsigned ncell_cap;
     unsigned scan_segments;             // blocks per replica of k_scan (the last one walks whatever is left)
+    int kx;                             // open boxes: cells are 1/kx of the list radius wide in x (a bead's row window is 2 kx + 1 cells =
+                                        // (2 + 1/kx) radii instead of 3); periodic grids: 1
     const float4 *pos_in;               // current order
     float4 *pos_out;                    // new (sorted) order
     float4 *xb;
     const unsigned *orig_in;
     unsigned *orig_out;
     unsigned *slot_of;                  // [R][N]
-    unsigned *cell_id, *rank;           // [R*Np]
-    unsigned *cell_cnt, *cell_start;    // [R][ncell_cap+1]
-    float *bbox;                        // [R][nblk][6] per-block bounding-box partials
+    unsigned *rank;                     // [R*Np] position of the bead inside its cell (k_bin)
+    unsigned *cell_cnt, *cell_start;    // [R][ncell_cap+1]; the counters are zero between builds (k_fill clears the cells a build used)
+    float *bbox;                        // [R][nblk][6] per-block bounding-box partials (k_bbox: builds without a bounding box from the build before)
+    // Open boxes: the bounding box of the positions a build sorted (k_scatter: one partial per wave, reduced by the extra blocks of
+    // k_tiles) is the box the NEXT build lays its grid on -- beads move less than the skin in between and cell_coords clamps to the
+    // grid, so any box gives correct lists, a stale one slightly fuller boundary cells; the first build of a handle, every build after
+    // gd_set_positions or a rolled-back chunk, and builds of generic lists (no k_tiles) run k_bbox + k_gridp instead.
+    const float *bbox_cur;              // [R][6] lo[3], hi[3] (warm builds read it)
+    float *bbox_next;                   // [R][6] written by k_tiles
+    float *bbox_w;                      // [R][nblk * GD_BLOCK / 64][6] per-wave partials of k_scatter
+    int warm;                           // 1: k_bin lays the grid itself (from bbox_cur, or from the periodic box); 0: k_bbox + k_gridp ran first
     GridP *grid;
     // static per-bead (bead order)
     const float2 *ab_o;
@@ -252,7 +262,6 @@ struct BuildParams {
     int has_bend, mob_is_uniform;
     unsigned short *nbr16;
     TileDesc *tiles;
-    unsigned *cell_s;                   // cell of each new slot
     unsigned W;
     int tiled, packed_ab;
     int w_valid;                        // pos_in.w already holds the packed (a,b) (written by an earlier build, kept by every step)
