@@ -1034,8 +1034,14 @@ static uint32_t interval_for_skin(const gd_system *s, double skin);
 static void take_pending_skin(gd_system *s)
 {
     if (!(s->skin_next > 0)) return;
+    // the interval follows the square of the skin (diffusive displacements) from the interval the handle had adapted to at the old width --
+    // a tenth off on the way up -- and not beyond what the measured displacement rate admits: the rate alone, averaged over a few
+    // intervals of a state that had just changed its regime, put S-genome-30k without second bonds at 23 steps where 19-20 hold
+    // (one rolled-back chunk in the timed steps of that line)
+    const double ratio = s->skin > 0 ? s->skin_next / s->skin : 1.0;
+    const uint32_t k_scaled = (uint32_t)std::max(1.0, std::floor((double)s->K * ratio * ratio * (ratio > 1.0 ? 0.9 : 1.0)));
     s->skin = s->skin_next; s->skin_next = 0;
-    s->K = interval_for_skin(s, s->skin); s->K_bad_ttl = 0;
+    s->K = std::min(interval_for_skin(s, s->skin), std::max(k_scaled, 1u)); s->K_bad_ttl = 0;
 }
 
 static int ensure_fresh_list(gd_system *s)
