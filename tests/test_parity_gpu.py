@@ -183,6 +183,50 @@ def test_neighbor_search_pair_set(hip, oracle, box):
     assert len(ph) > 100
 
 
+def test_lists_on_the_box_of_the_build_before(hip, oracle):
+    """Warm list builds lay their cell grid on the bounding box the build BEFORE recorded (gdyn_kernels.hip: k_scatter / k_tiles /
+    grid_warm): a free gas that doubles its extent during a run leaves that box at every build -- beads beyond it are clamped
+    into the boundary cells.  After the run the resident lists (built on such boxes, tiled path) give the oracle's forces and the
+    oracle's pair set on the same positions, for each of three replicas that expand at different rates; so does the first
+    build after gd_set_positions has moved the beads somewhere else entirely (a build with its own bounding-box pass)."""
+    R, n = 3, 6000
+    rng = np.random.default_rng(17)
+    x0 = ((rng.random((R, n, 3)) - 0.5) * np.array([2.0, 2.4, 2.8])).astype(np.float32).astype(np.float64)
+    def make(lib, r_count):
+        s = g.System(lib, n, r_count)
+        s.set_bead_params(a=(np.arange(n) % 2).astype(float), b=((np.arange(n) + 1) % 2).astype(float),
+                          mobility=np.ones(n))
+        s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
+        return s
+    sh = make(hip, R)
+    sh.set_tuning(kernel_path=2, rebuild_interval=3, adapt_interval=0)
+    sh.set_positions(x0)
+    sh.begin_phase()
+    b0 = sh.context().rebuilds
+    sh.run(240, 5e-5, 2.0, seed=SEED, replica_seeds=[11, 12, 13])       # sigma = 0.014 per step and axis: the cloud grows by ~0.5 per side
+    assert sh.context().rebuilds - b0 >= 60 and sh.context().list_path == 2
+    so = make(oracle, 1)
+    def check(xs):
+        Fh = sh.forces()
+        for r in range(R):
+            so.set_positions(xs[r])
+            Fo = so.forces()
+            assert np.abs(Fh[r] - Fo).max() <= FORCE_RTOL * max(np.abs(Fo).max(), 1.0)
+            ph = {tuple(p) for p in sh.search_pairs(0.3, replica=r)}
+            po = {tuple(p) for p in so.search_pairs(0.3)}
+            for i, j in ph ^ po:
+                assert abs(np.linalg.norm(xs[r][i] - xs[r][j]) - 0.3) < 1e-6
+            assert len(po) > 1000
+    x1 = sh.positions()
+    assert np.abs(x1).max() > np.abs(x0).max() + 0.1          # (it did leave the box it started in)
+    rb = sh.context().rebuilds
+    check(x1)
+    assert sh.context().rebuilds <= rb + 1
+    x2 = (x0[::-1] * 0.7 + np.array([5.0, -3.0, 2.0])).astype(np.float32).astype(np.float64)      # elsewhere, other extents: nothing of the old box applies
+    sh.set_positions(x2)
+    check(x2)
+
+
 def test_contact_pairs_from_the_resident_list(hip, oracle):
     """Contact-map / glue search (simulation_interphase/contact_map.cc:31-91, glues/glue_simulator.cpp:41,67-77) served
     from the Verlet list that is already on the device: S-genome-30k x 4 replicas, a few steps after a list build, search at
