@@ -810,9 +810,12 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
         if (s->W == 0) s->W = 96;
         s->W = (s->W + GD_UNROLL - 1) & ~(GD_UNROLL - 1);
         const size_t need = (size_t)s->W * s->R * s->Np;   // entries; chunked wave-interleaved layout (k_step)
-        // (grown on demand, given back when a dense transient has passed)
-        if (tiled) { if (s->nbr16.n < need || s->nbr16.n > 4 * need) HIPCHK(s->nbr16.resize(need, false)); }
-        else if (s->nbr.n < need || s->nbr.n > 4 * need) HIPCHK(s->nbr.resize(need, false));
+        // (grown on demand -- with an eighth to spare once the rows are long: the exact sizing of a dense start ends in a few builds
+        // that each ask for a handful of entries more, and every one of them used to free and allocate the whole 18 GB again --
+        // given back when a dense transient has passed)
+        const size_t grow = s->W >= 512 ? need + need / 8 : need;
+        if (tiled) { if (s->nbr16.n < need || s->nbr16.n > 4 * need) HIPCHK(s->nbr16.resize(grow, false)); }
+        else if (s->nbr.n < need || s->nbr.n > 4 * need) HIPCHK(s->nbr.resize(grow, false));
         s->list_W = s->W;
     }
     BuildParams b;
