@@ -1314,6 +1314,14 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
     const unsigned *cnt = p.cell_cnt + (size_t)r * (p.ncell_cap + 1);
     unsigned *start = p.cell_start + (size_t)r * (p.ncell_cap + 1);
     unsigned carry = 0;
+    // (the counts of the block's own first tile are requested before those in front of it: one memory round trip for both)
+    unsigned pre[GD_SCAN_TILE / 1024];
+    {
+        const unsigned m0 = min(GD_SCAN_TILE, n - t0);
+#pragma unroll
+        for (unsigned j = 0; j < GD_SCAN_TILE / 1024; j++) pre[j] = tid + j * 1024 < m0 ? cnt[t0 + tid + j * 1024] : 0u;
+    }
+    bool first_tile = true;
     if (t0 > 0) {      // sum of everything in front of this segment
         unsigned a = 0;
         for (unsigned i = tid; i < t0; i += 1024) a += cnt[i];
@@ -1325,7 +1333,11 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
     }
     for (;; t0 += GD_SCAN_TILE) {
         const unsigned m = min(GD_SCAN_TILE, n - t0);
-        for (unsigned i = tid; i < m; i += 1024) s_val[i] = cnt[t0 + i];
+        if (first_tile) {
+#pragma unroll
+            for (unsigned j = 0; j < GD_SCAN_TILE / 1024; j++) if (tid + j * 1024 < m) s_val[tid + j * 1024] = pre[j];
+            first_tile = false;
+        } else for (unsigned i = tid; i < m; i += 1024) s_val[i] = cnt[t0 + i];
         __syncthreads();
         const unsigned per = GD_SCAN_TILE / 1024, b = tid * per;
         unsigned s = 0;
@@ -1357,6 +1369,10 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
 // (dz,dy), in the linear range [c0+off-kx, c1+off+kx] with off = (dz*ny + dy)*nx (a superset; kx cells in x are one list radius).
 // (One thread per block of slots.  Run by one thread of the k_scatter block (r, blk) instead -- its index arrays live in scratch memory,
 // and a kernel that needs scratch runs few waves at a time -- k_scatter took 914 us instead of 60.)
+// PERIODIC = false: straight-line code over the nine (dz,dy) ranges -- every array index is a compile-time constant, so the ranges
+// live in registers and the 27 reads of the cell table are in flight together (the looped form kept its index arrays in scratch
+// memory and read the table range by range: 16 us per build, 10 us of a single replica's).
+template <bool PERIODIC>
 __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
 {
     const unsigned nb_tiles = (p.R * p.nblk + 63u) / 64u;
@@ -1385,12 +1401,11 @@ __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
     {
         const float4 xa = p.pos_out[rbase + first], xz = p.pos_out[rbase + last];
         int ax, ay, az, zx, zy, zz;
-        if (p.periodic) { cell_coords<true>(gp, xa, p.inv_box, ax, ay, az); cell_coords<true>(gp, xz, p.inv_box, zx, zy, zz); }
-        else { cell_coords<false>(gp, xa, p.inv_box, ax, ay, az); cell_coords<false>(gp, xz, p.inv_box, zx, zy, zz); }
+        cell_coords<PERIODIC>(gp, xa, p.inv_box, ax, ay, az); cell_coords<PERIODIC>(gp, xz, p.inv_box, zx, zy, zz);
         c0 = (az * gp.nc[1] + ay) * gp.nc[0] + ax; c1 = (zz * gp.nc[1] + zy) * gp.nc[0] + zx;
     }
     TileDesc td;
-    if (p.periodic) {
+    if (PERIODIC) {
         // Periodic boxes: the tile is made of WHOLE rows of cells (a row = fixed (z,y), all x; the x-neighbours of the
         // first and last cell of a row are in the same row).  Rows needed = the 3 x 3 (dz,dy) neighbours, wrapped, of
         // every row the block touches; consecutive rows are contiguous in slot order and merge into one range.
@@ -1453,43 +1468,69 @@ __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
         p.tiles[t] = td;
         return;
     }
-    // the 9 (dz,dy) cell ranges come out ordered by their first cell; merge the overlapping ones
-    int mlo[GD_TILE_RANGES], mhi[GD_TILE_RANGES], klo[GD_TILE_RANGES], kin[GD_TILE_RANGES], nm = 0;
-    for (int k = 0; k < GD_TILE_RANGES; k++) {
+    // the 9 (dz,dy) cell ranges come out ordered by their first cell; overlapping and adjacent ones merge.  (hi grows with k, so the
+    // largest hi so far is the hi of the merged range in progress.)
+    constexpr int NR = GD_TILE_RANGES;
+    int lo[NR], hi[NR], mid[NR];
+    bool val[NR], head[NR];
+    int nm = 0, hprev = 0;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
         const int dz = k / 3 - 1, dy = k % 3 - 1;
         const int off = (dz * gp.nc[1] + dy) * gp.nc[0];
-        const int lo = max(c0 + off - p.kx, 0), hi = min(c1 + off + p.kx, gp.ncell - 1);      // (kx cells in x are one list radius)
-        klo[k] = lo; kin[k] = -1;
-        if (lo > hi) continue;
-        if (nm > 0 && lo <= mhi[nm - 1] + 1) mhi[nm - 1] = max(mhi[nm - 1], hi);
-        else { mlo[nm] = lo; mhi[nm] = hi; nm++; }
-        kin[k] = nm - 1;
+        lo[k] = max(c0 + off - p.kx, 0); hi[k] = min(c1 + off + p.kx, gp.ncell - 1);      // (kx cells in x are one list radius)
+        val[k] = lo[k] <= hi[k];
+        head[k] = val[k] && (!any || lo[k] > hprev + 1);
+        if (head[k]) nm++;
+        mid[k] = nm - 1;
+        if (val[k]) { hprev = any ? max(hprev, hi[k]) : hi[k]; any = true; }
     }
+    int mlo[NR], mhi[NR];
+#pragma unroll
+    for (int m = 0; m < NR; m++) { mlo[m] = 0; mhi[m] = 0; }
+#pragma unroll
+    for (int k = 0; k < NR; k++)
+#pragma unroll
+        for (int m = 0; m <= k; m++)
+            if (val[k] && mid[k] == m) { if (head[k]) mlo[m] = lo[k]; mhi[m] = hi[k]; }
+    // every read of the cell table, unconditionally (an index of a range that does not exist is 0)
+    unsigned st[NR], en[NR], ks[NR];
+#pragma unroll
+    for (int m = 0; m < NR; m++) { st[m] = cs[m < nm ? mlo[m] : 0]; en[m] = cs[m < nm ? mhi[m] + 1 : 0]; }
+#pragma unroll
+    for (int k = 0; k < NR; k++) ks[k] = cs[val[k] ? lo[k] : 0];
     unsigned total = 0;
     bool truncated = false;
-    for (int k = 0; k < GD_TILE_RANGES; k++) {
-        unsigned st = 0, len = 0;
-        if (k < nm) { st = cs[mlo[k]]; len = cs[mhi[k] + 1] - st; }
+#pragma unroll
+    for (int m = 0; m < NR; m++) {
+        const unsigned s0 = m < nm ? st[m] : 0u;
+        unsigned len = m < nm ? en[m] - st[m] : 0u;
         if (total + len > p.tile_cap) {   // does not fit the LDS budget: flag, host rolls back and re-plans
             if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
             if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total + len);
             len = 0; truncated = true;
         }
-        td.start[k] = st; td.len[k] = len; td.base[k] = total;
+        td.start[m] = s0; td.len[m] = len; td.base[m] = total;
         total += len;
     }
-    for (int k = 0; k < GD_TILE_RANGES; k++) {
-        td.kstart[k] = 0xffffffffu; td.kbase[k] = 0;
-        if (kin[k] >= 0 && !truncated) {
-            const unsigned ks = cs[klo[k]];
-            td.kstart[k] = ks; td.kbase[k] = td.base[kin[k]] + (ks - td.start[kin[k]]);
+    unsigned own_base = 0;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        unsigned kstart = 0xffffffffu, kbase = 0;
+        if (val[k] && !truncated) {
+            unsigned b0 = 0, s0 = 0;
+#pragma unroll
+            for (int m = 0; m <= k; m++) if (mid[k] == m) { b0 = td.base[m]; s0 = td.start[m]; }
+            kstart = ks[k]; kbase = b0 + (ks[k] - s0);
         }
+        td.kstart[k] = kstart; td.kbase[k] = kbase;
+        if (k < nm && !truncated && first - td.start[k] < td.len[k]) own_base = td.base[k] + (first - td.start[k]);
     }
     td.nranges = truncated ? 0u : (unsigned)nm;
     td.total = total;
-    td.own_base = 0;
-    for (int k = 0; k < nm && !truncated; k++)
-        if (first - td.start[k] < td.len[k]) td.own_base = td.base[k] + (first - td.start[k]);
+    td.own_base = own_base;
+    td.pad_[0] = 0; td.pad_[1] = 0;
 
     if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
     p.tiles[t] = td;
@@ -1939,7 +1980,8 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
     hipLaunchKernelGGL(k_scan, dim3(p.R, std::max(1u, p.scan_segments)), dim3(1024), 0, st, p);
     if (p.periodic) hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p);
-    if (p.tiled) hipLaunchKernelGGL(k_tiles, dim3((p.R * p.nblk + 63) / 64 + (p.periodic ? 0u : p.R)), dim3(64), 0, st, p);
+    if (p.tiled && p.periodic) hipLaunchKernelGGL(k_tiles<true>, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
+    else if (p.tiled) hipLaunchKernelGGL(k_tiles<false>, dim3((p.R * p.nblk + 63) / 64 + p.R), dim3(64), 0, st, p);
     if (p.tiled) {
         static bool once = false;
         if (!once) {
