@@ -1151,8 +1151,12 @@ static void tune_skin(gd_system *s, double ms, int64_t steps, bool full_interval
             const unsigned est = (unsigned)(1.08 * s->last_need_t * (r1 / r0) * (r1 / r0)) + 32u;
             s->tile_cap = std::min(pick_tile_cap(est), 8192u); s->tile_hold = 0;
         }
-        s->skin = t.cand[next];
-        s->K = interval_for_skin(s, s->skin); s->K_bad_ttl = 0;
+        {      // (the interval as in take_pending_skin: from the one adapted to at the width in use, not beyond the measured rate)
+            const double ratio = s->skin > 0 ? t.cand[next] / s->skin : 1.0;
+            const uint32_t k_scaled = (uint32_t)std::max(1.0, std::floor((double)s->K * ratio * ratio * (ratio > 1.0 ? 0.9 : 1.0)));
+            s->skin = t.cand[next];
+            s->K = std::min(interval_for_skin(s, s->skin), k_scaled); s->K_bad_ttl = 0;
+        }
         s->list_valid = false;
         if (s->kernel_path != 1 && s->packed_ab) { s->tiled_ok = true; s->tiled_off = 0; }      // smaller tiles may fit now
     }
