@@ -1060,7 +1060,9 @@ static int ensure_fresh_list(gd_system *s)
 
 static hipEvent_t get_event(gd_system *s, size_t i)
 {
-    while (s->events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; s->events.push_back(e); }
+    // (timing events only: no system-scope fence when one is recorded -- the cache write-back and invalidation of the default event
+    // idle the device for ~5 us between the kernels on either side; what the host reads of a chunk it reads behind hipStreamSynchronize)
+    while (s->events.size() <= i) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr; s->events.push_back(e); }
     return s->events[i];
 }
 
