@@ -19,6 +19,7 @@
 #include <hip/hip_fp16.h>
 
 #include "gdyn_types.h"
+#include "gdyn_once.hpp"
 #ifdef GD_DEV
 #include "gdyn_dev.h"
 #endif
@@ -150,7 +151,7 @@ struct gd_system {
     DevBuf<unsigned> badj_o; DevBuf<int4> chain_o; DevBuf<BondType> btab;
     // device: per slot
     DevBuf<float4> pos[2], xb, fout, snap;
-    DevBuf<unsigned> orig[2], slot_of, rank, cell_cnt, cell_start, nbr, meta, badj, flags;
+    DevBuf<unsigned> orig[2], slot_of, rank, members, cell_cnt, cell_start, nbr, meta, badj, flags;
     DevBuf<float> bbox_enc, bbox_w;      // box of the last build's positions (two halves: read / written), k_scatter's per-wave partials
     int bbox_cur = 0;              // half of bbox_enc the next build reads (the other one is accumulated by it)
     bool bbox_valid = false;       // open boxes: bbox_enc[bbox_cur] holds the bounding box of the positions the last build sorted
@@ -226,6 +227,12 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
         return fail(GD_ENODEVICE, "gd_create: no HIP device visible (libgdyn has no CPU fallback)");
     if (d->device < 0 || d->device >= ndev) return fail(GD_ENODEVICE, "gd_create: device %d not in [0,%d)", d->device, ndev);
     HIPCHK(hipSetDevice(d->device));
+    {   // per-device set-up (LDS opt-in of the kernels): once per device ordinal, complete before any handle on it exists
+        static gd::DeviceOnce<> once;
+        const int rc = once.run(d->device, [](int) { return (int)gd_kernels_init_device(); });
+        if (rc != (int)hipSuccess)
+            return fail(GD_EHIP, "gd_create: kernel set-up on device %d failed: %s", d->device, rc < 0 ? "device ordinal beyond the guard's table" : hipGetErrorString((hipError_t)rc));
+    }
     gd_system *s = new (std::nothrow) gd_system();
     if (!s) return fail(GD_ENOMEM, "gd_create: out of host memory");
     s->N = d->n_beads; s->R = d->n_replicas; s->device = d->device; s->box_kind = d->box_kind;
@@ -251,7 +258,7 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
              s->react_part[k].resize((size_t)s->R * s->nblk) == hipSuccess;
     }
     ok = ok && s->xb.resize(RNp) == hipSuccess && s->slot_of.resize(RN) == hipSuccess && s->bbox_enc.resize((size_t)2 * s->R * 6) == hipSuccess && s->bbox_w.resize((size_t)s->R * s->nblk * (GD_BLOCK / 64) * 6) == hipSuccess &&
-         s->rank.resize(RNp) == hipSuccess && s->cell_cnt.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess &&
+         s->rank.resize(RNp) == hipSuccess && s->members.resize(RNp) == hipSuccess && s->cell_cnt.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess &&
          s->cell_start.resize((size_t)s->R * (s->ncell_cap + 1)) == hipSuccess && s->meta.resize(RNp) == hipSuccess &&
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
@@ -503,6 +510,7 @@ static void launch_softwell(gd_system *s, const StepParams &p, int mode)
     q.pos_in = p.pos_in; q.pos_out = p.pos_out; q.fout = s->fout.p; q.esum = s->sw_esum.p;
     q.slot_of = s->slot_of.p; q.targets = s->sw_targets.p;
     q.mob_o = s->mob_uniform >= 0.f ? nullptr : s->mob_o.p; q.mob_uniform = s->mob_uniform; q.dt = p.dt;
+    q.lo = p.lo; q.comp = p.comp;      // (a compensated step keeps the droplet's share of mu F dt in the residuals too)
     q.eps = (float)s->sw_eps; q.inv_d2 = (float)(1.0 / (s->sw_decay * s->sw_decay)); q.rc2 = (float)(s->sw_cut * s->sw_cut);
     q.N = s->N; q.Np = s->Np; q.R = s->R; q.M = s->sw_n;
     q.periodic = s->box_kind == GD_BOX_PERIODIC;
@@ -577,7 +585,9 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (!s || !t) return fail(GD_EINVAL, "gd_set_tuning: NULL argument");
     if (t->kernel_path > 2) return fail(GD_EINVAL, "gd_set_tuning: kernel_path must be 0..2");      // (validated before any state changes)
     if (t->near_fraction < 0 || t->near_fraction > 1) return fail(GD_EINVAL, "gd_set_tuning: near_fraction must be in [0,1]");
+    HIPCHK(hipSetDevice(s->device));
     if (t->skin > 0) { s->skin = t->skin; s->skin_fixed = true; }
+    else if (t->skin < 0) { s->skin = 0.75; s->skin_fixed = false; s->skin_dense_from = 0; }      // back to the library's own choice
     s->skin_streak = 0; s->skin_hold = 0; s->skin_next = 0;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
     s->tuner = gd_system::SkinTuner{};
@@ -833,7 +843,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     }
     b.pos_in = s->pos[s->pcur].p; b.pos_out = s->pos[s->pcur ^ 1].p; b.xb = s->xb.p;
     b.orig_in = s->orig[s->ocur].p; b.orig_out = s->orig[s->ocur ^ 1].p; b.slot_of = s->slot_of.p;
-    b.rank = s->rank.p; b.cell_cnt = s->cell_cnt.p; b.cell_start = s->cell_start.p;
+    b.rank = s->rank.p; b.members = s->members.p; b.cell_cnt = s->cell_cnt.p; b.cell_start = s->cell_start.p;
     b.bbox = s->bbox.p; b.grid = s->grid.p;
     b.bbox_cur = s->bbox_enc.p + (size_t)s->bbox_cur * s->R * 6; b.bbox_next = s->bbox_enc.p + (size_t)(s->bbox_cur ^ 1) * s->R * 6;
     b.warm = (b.periodic || s->bbox_valid) ? 1 : 0; b.bbox_w = s->bbox_w.p;
@@ -871,12 +881,11 @@ static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (siz
 static unsigned pick_tile_cap(unsigned need)
 {
     // LDS is granted in 1280-byte granules (measured with 1184 B of static LDS: 3264 entries fit 3 blocks, 3318 do not; 720 B now)
-    static std::vector<unsigned> caps = {3312u, 4080u, 5072u, 8192u};      // (4080: the largest tile with byte-offset list entries)
-    static bool init = false;
-    if (!init) {      // experiment hook: GDYN_TILE_CAPS=a,b,c
-        if (const char *e = dev_env("GDYN_TILE_CAPS")) { caps.clear(); for (const char *q = e; *q;) { caps.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
-        init = true;
-    }
+    static const std::vector<unsigned> caps = [] {      // (initialised once, thread-safe; experiment hook of developer builds: GDYN_TILE_CAPS=a,b,c)
+        std::vector<unsigned> c = {3312u, 4080u, 5072u, 8192u};      // (4080: the largest tile with byte-offset list entries)
+        if (const char *e = dev_env("GDYN_TILE_CAPS")) { c.clear(); for (const char *q = e; *q;) { c.push_back((unsigned)strtoul(q, (char **)&q, 10)); if (*q == ',') q++; } }
+        return c;
+    }();
     for (unsigned c : caps) if (need <= c) return c;
     return need;     // > 8192: the caller falls back to the generic path
 }
@@ -1271,6 +1280,8 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         HIPCHK(s->snap_lo.resize(RN, false));
     }
     if (run->steps > 0) s->comp_last = comp;
+    if (run->steps > 0 && !comp) s->lo_valid = false;      // the positions are about to move without their residuals (set here, not on the way
+                                                          // out: an early error return must not leave residuals that describe other positions)
 
     if (run->replica_seeds) {
         static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "seed width");
@@ -1456,7 +1467,6 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         if (with_list && full_interval) class_skin(s, run);
         done += chunk;
     }
-    if (run->steps > 0 && !comp) s->lo_valid = false;      // the positions moved without their residuals
     // The last chunk was accepted: every bead is within the margin the list in use was built for, at the cutoff of the last step.
     // That is still the cutoff an observation sees when the scales did not move behind that step (callback deferred, or no scale
     // updates in this run) -- the resident list then serves gd_compute_energy as it is.

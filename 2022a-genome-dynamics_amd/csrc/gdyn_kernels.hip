@@ -1048,24 +1048,7 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
 {
     const dim3 grid(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk), block(GD_BLOCK);
     const size_t lds = p.tiled ? (size_t)p.tile_cap * sizeof(float4) : 0;
-    if (p.tiled) {   // opt in to more than 64 KB of LDS per block (gfx950: 160 KB per CU)
-        static bool once = false;
-        if (!once) {
-            once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, true, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<MODE, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        }
-    }
+    // (more than 64 KB of dynamic LDS: opted in per device at gd_create, gd_kernels_init_device below)
     const bool s16 = p.tiled && p.tile_cap < 4096u;      // must match k_fill's choice (gd_launch_build)
     // The LDS class of a launch is set by the LARGEST tile of any replica, and one tile a few beads over the three-block class
     // (3 312) costs every block a third of its occupancy (S-genome-62k x 64: a handful of tiles in the nucleus' centre).  While the
@@ -1077,14 +1060,6 @@ static void launch_step_mode(const StepParams &p, hipStream_t st)
     // 80 registers, so the blocks with small tiles run three to a CU next to the few large ones.)
     const unsigned split_at = !p.tiled ? 0u : (s16 && p.tile_cap > 3312u) ? 3312u : (!s16 && p.tile_cap > 5072u) ? 5072u : (!s16 && p.tile_cap > 3312u) ? 3312u : 0u;
     if (MODE == GD_MODE_STEP && split_at) {
-        static bool once_split = false;
-        if (!once_split) {
-            once_split = true;
-#define AS(PER, PK, S) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<GD_MODE_STEP, PER, true, PK, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)
-            AS(false, 0, true); AS(false, 1, true); AS(false, 2, true); AS(true, 0, true); AS(true, 1, true); AS(true, 2, true);
-            AS(false, 0, false); AS(false, 1, false); AS(false, 2, false); AS(true, 0, false); AS(true, 1, false); AS(true, 2, false);
-#undef AS
-        }
         StepParams q = p;
         for (int half = 0; half < 2; half++) {
             q.tile_cap = half ? p.tile_cap : split_at; q.tile_lo = half ? split_at : 0u; q.tile_hi = half ? 0xffffffffu : split_at;
@@ -1536,6 +1511,26 @@ __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
     p.tiles[t] = td;
 }
 
+// The ranks k_bin hands out are arrival orders of its atomics: they differ from run to run, and with them the order of the beads
+// inside a cell, the order of every list, the fp32 summation order of every force -- the trajectory (the reference is one thread
+// in fp64: one seed, one trajectory; 5-sim-genome/scripts/run_simulation:8-25, simulation_fine_sampling/simulation_driver.cc:44-54
+// restarts from a stored frame and relies on it).  k_members lists the bead ids of every cell (at the arrival rank, any order);
+// k_scatter then places a bead behind the members of its cell with a smaller id: slot order = (cell, bead id), a function of the
+// positions alone.
+template <bool PERIODIC>
+__global__ __launch_bounds__(GD_BLOCK) void k_members(const BuildParams p)
+{
+    const unsigned r = blockIdx.x / p.nblk, blk = blockIdx.x % p.nblk;
+    const unsigned slot = blk * GD_BLOCK + threadIdx.x;
+    if (slot >= p.N) return;
+    const size_t rbase = (size_t)r * p.Np, g = rbase + slot;
+    const GridP gp = p.grid[r];
+    int cx, cy, cz;
+    cell_coords<PERIODIC>(gp, p.pos_in[g], p.inv_box, cx, cy, cz);       // as k_bin found it
+    const unsigned c = (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx);
+    p.members[rbase + p.cell_start[(size_t)r * (p.ncell_cap + 1) + c] + p.rank[g]] = p.orig_in[g];
+}
+
 // Counting-sort scatter into the new slot order (+ the static per-slot data); open boxes: every wave also records the bounding box of
 // the positions it moves, for the next build's grid (the kernel is memory-bound: the reductions are free).
 template <bool PERIODIC>
@@ -1558,8 +1553,14 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
     int cx, cy, cz;
     cell_coords<PERIODIC>(gp, x, p.inv_box, cx, cy, cz);       // as k_bin found it
     const unsigned c = (unsigned)((cz * gp.nc[1] + cy) * gp.nc[0] + cx);
-    const unsigned ns = p.cell_start[(size_t)r * (p.ncell_cap + 1) + c] + p.rank[g];
     const unsigned o = p.orig_in[g];
+    // rank inside the cell by bead id (the members of a cell share a cache line or two; the lanes of a wave sit in a handful of cells)
+    const unsigned c_lo = p.cell_start[(size_t)r * (p.ncell_cap + 1) + c], c_hi = p.cell_start[(size_t)r * (p.ncell_cap + 1) + c + 1];
+    unsigned ns = c_lo;
+    {
+        const unsigned *__restrict__ mem = p.members + rbase;
+        for (unsigned q = c_lo; q < c_hi; q++) ns += mem[q] < o ? 1u : 0u;
+    }
     // (a,b) ride in pos.w and every kernel carries w along: only positions that came from the host (w = 0) need the per-bead
     // gather again
     float2 ab = make_float2(0.f, 0.f);
@@ -1625,11 +1626,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     if (TILED) {
         // (two barriers: histogram cleared + descriptor copied | histogram complete; every wave then scans the 64 bins itself.
         // The first barrier also waits for the tile DMAs issued above.)
-        __shared__ unsigned s_hist[64];
-        if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+        // (the order is STABLE -- by bin, then by slot: ranks handed out by an LDS atomic would be arrival orders, and the thread a bead
+        // lands on decides the order in which the wall-reaction partials of a block are summed)
+        __shared__ unsigned s_hist[GD_BLOCK / 64][64];
+        s_hist[wid][lane] = 0;
         if (threadIdx.x >= 64 && threadIdx.x - 64 < sizeof(TileDesc) / 4) ((unsigned *)&s_tdesc)[threadIdx.x - 64] = ((const unsigned *)tdp)[threadIdx.x - 64];
         unsigned bin = 63u;                                        // slots past N: last
         if (slot < p.N) bin = 62u - min((unsigned)p.len_prev[(size_t)r * p.N + o_pre], 62u);
+        // lanes of the wave in the same bin (six ballots), the thread's rank among them, their number
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int bit = 0; bit < 6; bit++) {
+            const bool on = (bin >> bit) & 1u;
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(on);
+            same &= on ? b : ~b;
+        }
+        const unsigned rank_w = (unsigned)__popcll(same & ((1ull << lane) - 1ull));
         __syncthreads();
         if (PERIODIC) {
             // Periodic boxes: wrap the staged tile into [0, L) in place (coordinates are kept unwrapped in memory: a chain that has
@@ -1643,12 +1655,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 s_tile[t] = x;
             }
         }
-        const unsigned rank = atomicAdd(&s_hist[bin], 1u);
+        if (rank_w == 0u) s_hist[wid][bin] = (unsigned)__popcll(same);
         __syncthreads();
-        unsigned incl = s_hist[lane];
+        // lane b stands for bin b: threads of the block in that bin, and those of them in the waves in front of this one
+        unsigned incl = 0, before = 0;
+#pragma unroll
+        for (unsigned w = 0; w < GD_BLOCK / 64; w++) { const unsigned v = s_hist[w][lane]; incl += v; before += w < wid ? v : 0u; }
         const unsigned own = incl;
         for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
-        gt = rbase + blk * GD_BLOCK + (unsigned)__shfl((int)(incl - own), (int)bin, 64) + rank;
+        gt = rbase + blk * GD_BLOCK + (unsigned)__shfl((int)(incl - own + before), (int)bin, 64) + rank_w;
     }
     GD_FSTAMP(0);     // staging + barrier
     unsigned cnt = 0;
@@ -1978,19 +1993,11 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
         hipLaunchKernelGGL((k_bin<false, false>), grid, block, 0, st, p);
     }
     hipLaunchKernelGGL(k_scan, dim3(p.R, std::max(1u, p.scan_segments)), dim3(1024), 0, st, p);
-    if (p.periodic) hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p);
+    if (p.periodic) { hipLaunchKernelGGL(k_members<true>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p); }
+    else { hipLaunchKernelGGL(k_members<false>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p); }
     if (p.tiled && p.periodic) hipLaunchKernelGGL(k_tiles<true>, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
     else if (p.tiled) hipLaunchKernelGGL(k_tiles<false>, dim3((p.R * p.nblk + 63) / 64 + p.R), dim3(64), 0, st, p);
     if (p.tiled) {
-        static bool once = false;
-        if (!once) {
-            once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        }
         const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
         if (p.periodic) {
             if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p);
@@ -2039,7 +2046,18 @@ __global__ __launch_bounds__(256) void k_softwell(const SoftwellP p)
             const float mu_dt = (p.mob_o ? p.mob_o[bead] : p.mob_uniform) * p.dt;
             float4 *o = p.pos_out + (size_t)r * p.Np + so[bead];
             float4 x = *o;
-            x.x += mu_dt * F.x; x.y += mu_dt * F.y; x.z += mu_dt * F.z;
+            const float ex = mu_dt * F.x, ey = mu_dt * F.y, ez = mu_dt * F.z;
+            if (p.comp) {
+                // compensated runs (T = 0, dt = 1e-7: the droplet's share of mu F dt is around or below an ulp of the coordinate):
+                // the same two-sum over (x, lo) as k_step's update, on the pair k_step has just written
+                float4 *lp = p.lo + ((size_t)r * p.N + bead);
+                const float4 l = *lp;
+                const float tx = l.x + ex, ty = l.y + ey, tz = l.z + ez;
+                const float nx = x.x + tx, ny = x.y + ty, nz = x.z + tz;
+                const float bx = nx - x.x, by = ny - x.y, bz = nz - x.z;
+                *lp = make_float4((x.x - (nx - bx)) + (tx - bx), (x.y - (ny - by)) + (ty - by), (x.z - (nz - bz)) + (tz - bz), 0.f);
+                x.x = nx; x.y = ny; x.z = nz;
+            } else { x.x += ex; x.y += ey; x.z += ez; }
             *o = x;
         }
     } else if (MODE == 1) {
@@ -2059,13 +2077,6 @@ void gd_launch_softwell(const SoftwellP &p, int mode, hipStream_t st)
 {
     const dim3 grid((p.M + 255) / 256, p.R), block(256);
     const size_t lds = (size_t)p.M * sizeof(float4);
-    static bool once = false;
-    if (!once) {
-        once = true;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softwell<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softwell<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_softwell<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    }
     if (mode == 0) hipLaunchKernelGGL(k_softwell<0>, grid, block, lds, st, p);
     else if (mode == 1) hipLaunchKernelGGL(k_softwell<1>, grid, block, lds, st, p);
     else hipLaunchKernelGGL(k_softwell<2>, grid, block, lds, st, p);
@@ -2249,6 +2260,36 @@ void gd_launch_contacts_compact(const ContactTab &t, unsigned r, unsigned long l
 {
     const unsigned nb = (unsigned)std::min<unsigned long long>((t.cap + 255ull) / 256ull, 8192ull);
     hipLaunchKernelGGL(k_ct_compact, dim3(nb), dim3(256), 0, st, t, r, keys_out, vals_out, n_out);
+}
+
+// ------------------------------------------------------- per-device set-up
+// Every kernel that takes more than 64 KB of dynamic LDS (gfx950: 160 KB per CU) opts in HERE, once per device, with checked
+// return codes -- called by gd_create under the per-device guard of gdyn_once.hpp, so that no launch on a device can precede it and
+// two threads creating handles at the same time do not race (until round 5 each launcher did this behind an unsynchronised
+// `static bool once`, per process: a second device never got the attribute).  The caller has made `device` current.
+hipError_t gd_kernels_init_device(void)
+{
+    hipError_t first = hipSuccess;
+    auto set = [&](const void *f, int bytes) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    };
+#define GD_AS(MODE, PER, PK, S, SP) set(reinterpret_cast<const void *>(&k_step<MODE, PER, true, PK, S, SP>), 128 * 1024)
+#define GD_AS_PK(MODE, PER, S, SP) GD_AS(MODE, PER, 0, S, SP); GD_AS(MODE, PER, 1, S, SP); GD_AS(MODE, PER, 2, S, SP)
+#define GD_AS_ALL(MODE, SP) GD_AS_PK(MODE, false, false, SP); GD_AS_PK(MODE, false, true, SP); GD_AS_PK(MODE, true, false, SP); GD_AS_PK(MODE, true, true, SP)
+    GD_AS_ALL(GD_MODE_STEP, false); GD_AS_ALL(GD_MODE_STEP, true);
+    GD_AS_ALL(GD_MODE_FORCE, false); GD_AS_ALL(GD_MODE_ENERGY, false);
+#undef GD_AS_ALL
+#undef GD_AS_PK
+#undef GD_AS
+    set(reinterpret_cast<const void *>(&k_fill<false, true, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_softwell<0>), 64 * 1024);
+    set(reinterpret_cast<const void *>(&k_softwell<1>), 64 * 1024);
+    set(reinterpret_cast<const void *>(&k_softwell<2>), 64 * 1024);
+    return first;
 }
 
 // ------------------------------------------------------------------- misc

@@ -231,7 +231,10 @@ struct BuildParams {
     const unsigned *orig_in;
     unsigned *orig_out;
     unsigned *slot_of;                  // [R][N]
-    unsigned *rank;                     // [R*Np] position of the bead inside its cell (k_bin)
+    unsigned *rank;                     // [R*Np] position of the bead inside its cell as the atomics of k_bin handed it out (arrival order)
+    unsigned *members;                  // [R*Np] bead ids by (cell, arrival rank) (k_members): k_scatter ranks a bead by its ID inside its cell,
+                                        // so the slot order -- and with it every fp32 summation order downstream -- is a function of the
+                                        // positions alone, not of the order in which the atomics of k_bin happened to arrive
     unsigned *cell_cnt, *cell_start;    // [R][ncell_cap+1]; the counters are zero between builds (k_fill clears the cells a build used)
     float *bbox;                        // [R][nblk][6] per-block bounding-box partials (k_bbox: builds without a bounding box from the build before)
     // Open boxes: the bounding box of the positions a build sorted (k_scatter: one partial per wave, reduced by the extra blocks of
@@ -274,6 +277,7 @@ struct BuildParams {
 };
 
 // launchers (gdyn_kernels.hip)
+hipError_t gd_kernels_init_device(void);      // LDS opt-in of every kernel that needs it, on the current device (once per device: gd_create)
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
 void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st);     // k_ctx: 0 final callback, 1 fold reaction partials
 void gd_launch_build(const BuildParams &p, hipStream_t st);
@@ -286,6 +290,8 @@ struct SoftwellP {
     const unsigned *slot_of, *targets;
     const float *mob_o;         // per-bead mobility, or NULL with mob_uniform
     float mob_uniform, dt, eps, inv_d2, rc2;
+    float4 *lo;                 // mode 0 with comp: residuals of the compensated update, [R][N] by bead (k_step has normalised (x, lo) already)
+    int comp;
     unsigned N, Np, R, M;
     int periodic;
     float box[3], inv_box[3];

@@ -72,13 +72,18 @@ def replica_seed(master_seed, rank):
     return int(master_seed) + 1000003 * int(rank)
 
 
-def bind_to_cpu_share(local_rank, local_world):
+def bind_to_cpu_share(local_rank, local_world, cpus_per_gpu=16):
     """Bind this rank to its GPU's share of the CPUs the process may run on (share `local_rank` of `local_world`, contiguous;
-    the GPU box grants 16 CPUs per GPU): the launch threads of eight ranks -- one host thread + one stream per device -- then do
-    not migrate over, or contend with, one another.  Returns the CPUs of the share (the whole set when it cannot be split)."""
+    the GPU box grants `cpus_per_gpu` = 16 CPUs per GPU): the launch threads of eight ranks -- one host thread + one stream per
+    device -- then do not migrate over, or contend with, one another.  Only an affinity the local ranks SHARE is split: a set of
+    at most `cpus_per_gpu` CPUs on a machine that has more is taken to be this rank's own share already (a launcher, numactl or
+    a scheduler cpuset pinned it) and is kept -- cutting it again would leave 2 CPUs for the stepping thread, the packing pool and
+    the writer.  `GDYN_NO_BIND=1` (bench.py --no-bind) keeps whatever the process inherited.  Returns the CPUs of the share."""
     import os
     cpus = sorted(os.sched_getaffinity(0))
-    if local_world <= 1 or len(cpus) < local_world:
+    if os.environ.get("GDYN_NO_BIND") or local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    if len(cpus) <= cpus_per_gpu and (os.cpu_count() or 0) > len(cpus):
         return cpus
     per = len(cpus) // local_world
     share = cpus[local_rank * per:(local_rank + 1) * per if local_rank < local_world - 1 else len(cpus)]

@@ -11,8 +11,10 @@
 //
 // Options beyond the reference's: -d <device>; --trace <dir> (test support): writes <dir>/init.f64 (initial positions) and
 // <dir>/trace.txt with the integrator seed and every loop / glue list uploaded, so a run can be replayed call by call;
-// --fixed-skin: keep the library's default list width instead of letting it select one from measured chunk times (the
-// selection changes cost only, but also the cell decomposition and with it the fp32 summation order of a trajectory).
+// --auto-skin: let the library select the list width from measured chunk times (gd_tuning.auto_skin).  Off by default: the
+// selection changes cost only, but it reads a clock -- the cell decomposition, and with it the fp32 summation order of a
+// trajectory, would differ from run to run, where the reference gives one trajectory per seed.  (--fixed-skin, the former
+// spelling of the default, is still accepted.)
 // The program reads no environment variable.
 #include <algorithm>
 #include <cmath>
@@ -88,7 +90,7 @@ gd::loop_extruder make_loop_extruder(simulation_config const &config, std::vecto
 
 class simulation {
 public:
-    simulation(simulation_config const &config, int device, std::string const &trace_dir = "", bool auto_skin = true)
+    simulation(simulation_config const &config, int device, std::string const &trace_dir = "", bool auto_skin = false)
         : _config(config), _random(make_random(config.sampling.random_seed)), _store(config.sampling.output_filename),
           _chains(make_chain_assignments(_config)), _loops(make_loop_extruder(_config, _chains)),
           _glues(_config.glue.max_glues, _config.glue.glue_distance, _config.glue.glue_binding_rate, _config.glue.glue_unbinding_rate,
@@ -121,7 +123,7 @@ private:
         desc.n_beads = (uint32_t)_n; desc.n_replicas = 1; desc.device = device; desc.box_kind = GD_BOX_PERIODIC;
         desc.box[0] = desc.box[1] = desc.box[2] = ch.box_size;
         chk(gd_create(&desc, &_sys));
-        {   // the list width for this model's density and cutoff: selected by the library from measured chunk times
+        {   // the list width: the library's state-based default, or (--auto-skin) selected from measured chunk times
             gd_tuning tune{};
             tune.adapt_interval = 1; tune.auto_skin = _auto_skin ? 1 : 0;
             chk(gd_set_tuning(_sys, &tune));
@@ -301,7 +303,7 @@ private:
     std::vector<double> _xyz;
     std::string _trace_dir;
     std::ofstream _trace;
-    bool _auto_skin = true;
+    bool _auto_skin = false;
 };
 
 void show_usage()
@@ -314,7 +316,8 @@ void show_usage()
                  "  -o <output>  override output HDF5 filename (config 'output_filename' key)\n"
                  "  -s <seed>    override random seed (config 'random_seed' key)\n"
                  "  -d <device>  GPU index (default 0)\n"
-                 "  --fixed-skin keep the default neighbour-list width (no selection from measured step times)\n"
+                 "  --auto-skin  select the neighbour-list width from measured step times (faster on some models; the\n"
+                 "               trajectory of a seed then depends on timing -- off by default)\n"
                  "  --trace <dir> write the initial positions and every uploaded loop / glue list to <dir> (replay support)\n"
                  "  -h           print this usage message and exit\n\n";
 }
@@ -337,7 +340,7 @@ int main(int argc, char **argv)
         std::vector<std::string> positional;
         int device = 0;
         std::string trace_dir;
-        bool auto_skin = true;
+        bool auto_skin = false;
         for (int i = 1; i < argc; i++) {
             std::string const arg = argv[i];
             auto value = [&]() -> std::string { if (i + 1 >= argc) throw std::runtime_error{"bad option"}; return argv[++i]; };
@@ -347,6 +350,7 @@ int main(int argc, char **argv)
             else if (arg == "-s") seed = std::stoull(value());
             else if (arg == "-d") device = std::stoi(value());
             else if (arg == "--trace") trace_dir = value();
+            else if (arg == "--auto-skin") auto_skin = true;
             else if (arg == "--fixed-skin") auto_skin = false;
             else if (arg.size() > 1 && arg[0] == '-') throw std::runtime_error{"bad option"};
             else positional.push_back(arg);

@@ -83,7 +83,7 @@ std::vector<std::array<std::uint32_t, 3>> fetch_contacts(gd_system *sys, uint32_
 // (gd_run_desc.replica_seeds), so a batched trajectory equals the solo one up to fp32 summation order.
 class simulation_driver {
 public:
-    simulation_driver(std::vector<std::unique_ptr<gd::trajectory_store>> &stores, int device, bool auto_skin = true)
+    simulation_driver(std::vector<std::unique_ptr<gd::trajectory_store>> &stores, int device, bool auto_skin = false)
         : _stores(stores), _R(stores.size()), _config(gd::parse_simulation_config(stores[0]->load_config_text())), _auto_skin(auto_skin)
     {
         // compatibility defaults of older runs (simulation_driver.cc:20-29)
@@ -151,8 +151,9 @@ private:
         c.wall_semiaxes[2] = _config.wall_init_semiaxes.z;
         c.bead_scale = _config.bead_scale_init; c.bond_scale = _config.bond_scale_init;
         _context.assign(_R, c);
-        {   // the list width follows the structure: a freshly refined genome is a dense globule (hundreds of list entries per bead
-            // at the default width) that decondenses over the run -- selected by the library from measured chunk times
+        {   // the list width follows the structure (a freshly refined genome is a dense globule that decondenses over the run): by
+            // the library's rules on the state -- tile class, rows sized per wave -- so that a seed gives one trajectory, as in
+            // the reference (scripts/run_simulation:8-25); --auto-skin selects it from measured chunk times instead
             gd_tuning tune{};
             tune.adapt_interval = 1; tune.auto_skin = _auto_skin ? 1 : 0;
             chk(gd_set_tuning(_sys, &tune));
@@ -363,7 +364,7 @@ private:
     std::vector<std::unique_ptr<gd::trajectory_store>> &_stores;
     std::size_t _R;
     gd::simulation_config _config;
-    bool _auto_skin = true;
+    bool _auto_skin = false;
     std::vector<gd::context> _context;
     double _contact_distance = 0;
     std::vector<std::mt19937_64> _random;
@@ -383,15 +384,17 @@ int main(int argc, char **argv)
 {
     // gd_interphase <trajectory> [device]                      the reference's command line
     // gd_interphase [--device d] <trajectory> <trajectory>...  R prepared files as R replicas of one handle
-    // options: --timing (wall-time split on stderr at the end), --fixed-skin (no list-width selection)
+    // options: --timing (wall-time split on stderr at the end), --auto-skin (list width selected from measured chunk times: the
+    // trajectory of a seed then depends on timing; off by default.  --fixed-skin, the former spelling of the default, is accepted)
     std::vector<std::string> files;
     int device = 0;
-    bool timing = false, auto_skin = true;
+    bool timing = false, auto_skin = false;
     auto const t_start = std::chrono::steady_clock::now();
     for (int i = 1; i < argc; i++) {
         std::string const arg = argv[i];
         if (arg == "--timing") timing = true;
-        else if (arg == "--fixed-skin") auto_skin = false;      // keep the library's default list width (no selection sweeps)
+        else if (arg == "--auto-skin") auto_skin = true;
+        else if (arg == "--fixed-skin") auto_skin = false;
         else if (arg == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
         else files.push_back(arg);
     }

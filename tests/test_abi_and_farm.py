@@ -12,6 +12,8 @@ import pytest
 from conftest import ROOT
 from util import g
 
+PKG_DIR = "2022a-genome-dynamics_amd"
+
 
 def _built():
     if not os.path.exists(g.LIBGDYN_PATH):
@@ -211,3 +213,24 @@ def test_bench_gpus2_without_a_launcher_starts_its_own_ranks(hip):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0
     assert line["config"]["global_replicas"] == 16 and line["value"] > 0
+
+
+def test_per_device_setup_guard_runs_once_per_device_and_blocks_until_done(tmp_path):
+    """csrc/gdyn_once.hpp (the guard gd_create runs the kernels' LDS opt-in under): one set-up per device ordinal, no caller
+    past it before it has returned, the status kept -- 32 threads over 4 ordinals with a slow set-up (tests/native/test_once.cpp)."""
+    exe = str(tmp_path / "test_once")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, PKG_DIR, "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "test_once.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "once: ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_no_launcher_keeps_an_unsynchronised_once_flag():
+    """The kernels' per-device attributes are set in ONE place (gd_kernels_init_device, under the guard); no launcher may carry a
+    `static bool once` of its own again."""
+    src = open(os.path.join(ROOT, PKG_DIR, "csrc", "gdyn_kernels.hip")).read()
+    code = "\n".join(ln.split("//")[0] for ln in src.splitlines())
+    assert "static bool" not in code
+    assert code.count("hipFuncAttributeMaxDynamicSharedMemorySize") == 1      # (the one lambda of gd_kernels_init_device)
+    capi = open(os.path.join(ROOT, PKG_DIR, "csrc", "gdyn_capi.hip")).read()
+    assert "gd_kernels_init_device()" in capi and "DeviceOnce" in capi

@@ -1201,3 +1201,98 @@ def test_list_width_follows_the_tile_class(hip, oracle):
     s.begin_phase()
     s.run(1500, info["timestep"], info["temperature"], seed=SEED + 9, flags=0)
     assert abs(s.context().list_radius - cut * 1.75) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 5: one seed -> one trajectory; independent handles on independent host threads
+
+def _run_once_for_determinism(hip, n_beads, n_rep, relax, steps):
+    s, info = wl.genome_interphase(hip, n_beads=n_beads, n_replicas=n_rep)
+    s.set_tuning(kernel_path=PATHS["tiled"])
+    dt, kT = info["timestep"], info["temperature"]
+    s.begin_phase()
+    s.run(relax, dt, kT, seed=SEED + 5, flags=0)
+    s.begin_phase()
+    flags = g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS
+    c0 = s.context()
+    s.run(steps, dt, kT, seed=SEED, flags=flags)
+    _assert_path(s, "tiled")
+    s.contacts_update(0.4 * s.context().bead_scale)
+    out = dict(x=s.positions(), x32=s.positions_f32(), rows=[s.contacts(r) for r in (0, n_rep - 1)], e=s.energy(),
+               rebuilds=s.context().rebuilds - c0.rebuilds, K=s.context().rebuild_interval, semi=np.array(s.context().semiaxes),
+               react=np.array(s.context().axial_reaction))
+    s.close()
+    return out
+
+
+def test_same_seed_gives_the_same_trajectory_bit_for_bit(hip):
+    """The reference is one thread in fp64: one seed, one trajectory (5-sim-genome/scripts/run_simulation:8-25;
+    simulation_fine_sampling/simulation_driver.cc:44-54 restarts from a stored frame and relies on it).  On the device the order
+    of the beads inside a neighbour-search cell used to be the arrival order of atomics, and with it every list order and fp32
+    summation order: since round 5 the slot order is (cell, bead id) and the thread order inside a block is stable, so two runs of
+    the same handle set-up and seed are identical BIT FOR BIT -- positions (fp64 boundary and fp32), energies, wall state and the
+    contact-map rows -- over several rebuild intervals of the tiled path at 30 000 beads x 8 replicas."""
+    a = _run_once_for_determinism(hip, 30000, 8, 600, 90)
+    b = _run_once_for_determinism(hip, 30000, 8, 600, 90)
+    assert a["rebuilds"] >= 3 and a["rebuilds"] == b["rebuilds"] and a["K"] == b["K"], (a["rebuilds"], b["rebuilds"], a["K"], b["K"])
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["x32"], b["x32"])
+    assert np.array_equal(a["e"], b["e"]) and np.array_equal(a["semi"], b["semi"]) and np.array_equal(a["react"], b["react"])
+    for ra, rb in zip(a["rows"], b["rows"]):
+        assert len(ra) > 1000 and np.array_equal(ra, rb)
+
+
+def test_same_seed_same_trajectory_on_the_generic_and_periodic_paths(hip):
+    """The same property on the global-gather path and on a periodic box (whole-row tiles): 1 kb model, 3 replicas."""
+    outs = []
+    for path in ("generic", "tiled"):
+        pair = []
+        for _ in range(2):
+            s, dt, kT, flags = build(hip, "chromatin_1kb", n_replicas=3)
+            s.set_tuning(kernel_path=PATHS[path])
+            s.begin_phase()
+            s.run(120, dt, kT, seed=SEED, flags=flags)
+            _assert_path(s, path)
+            pair.append((s.positions(), s.context().rebuilds))
+            s.close()
+        assert pair[0][1] == pair[1][1] and pair[0][1] >= 2
+        assert np.array_equal(pair[0][0], pair[1][0]), path
+        outs.append(pair[0][0])
+
+
+def test_two_handles_on_two_host_threads_race_their_first_launches(hip, oracle):
+    """include/gdyn.h: independent handles may live on different threads (and devices).  Two tiled handles are created and stepped
+    from two host threads at the same time -- their first launches race through the per-device kernel set-up (the > 64 KB LDS
+    opt-in, once per device under std::call_once since round 5; it used to sit behind an unsynchronised `static bool once` in
+    every launcher) -- and each must match the oracle as a solo handle does."""
+    import threading
+    n_beads, steps = 4000, 30
+    results, errors = {}, []
+    gate = threading.Barrier(2)
+
+    def worker(k):
+        try:
+            gate.wait()
+            s, info = wl.genome_interphase(hip, n_beads=n_beads, n_replicas=2 + k, bead_scale_init=0.8)
+            s.set_tuning(kernel_path=PATHS["tiled"])
+            F = s.forces()
+            s.begin_phase()
+            s.run(steps, info["timestep"], info["temperature"], seed=SEED + k, flags=g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS)
+            results[k] = (F, s.positions(), s.context().list_path)
+            s.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for k in range(2):
+        so, info = wl.genome_interphase(oracle, n_beads=n_beads, n_replicas=2 + k, bead_scale_init=0.8)
+        Fo = so.forces()
+        so.begin_phase()
+        so.run(steps, info["timestep"], info["temperature"], seed=SEED + k, flags=g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS)
+        F, x, path = results[k]
+        assert path == PATHS["tiled"]
+        assert np.abs(F - Fo).max() <= FORCE_RTOL * np.abs(Fo).max()
+        assert np.abs(x - so.positions()).max() <= 2 * POS_ATOL_20STEP
+        so.close()
