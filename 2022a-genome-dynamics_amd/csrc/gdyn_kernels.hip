@@ -1583,11 +1583,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
     GD_FSTAMP_BEGIN();
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
-    __shared__ unsigned long long s_cnt[GD_BLOCK / 64];
-    __shared__ unsigned s_max[GD_BLOCK / 64];
+    // block totals (list entries, longest list): accumulated by LDS atomics as the waves finish; the last one to finish hands them on --
+    // no barrier at the end of the kernel, a wave that is done leaves.  (Static LDS is budgeted: with the tile class of 3 312 entries
+    // three blocks fit a CU only up to 704 bytes of it -- LDS is granted in 1 280-byte granules; tools/kregs.py shows the figure.)
+    __shared__ unsigned long long s_acc_cnt;
+    __shared__ unsigned s_acc_max, s_acc_done;
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_acc_cnt = 0ull; s_acc_max = 0u; s_acc_done = 0u; }
+    if (!TILED) __syncthreads();      // (the tiled path has its barriers below)
     const size_t rbase = (size_t)r * p.Np;
     const unsigned slot = blk * GD_BLOCK + threadIdx.x;
     size_t gt = rbase + slot;
@@ -1628,11 +1633,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         // The first barrier also waits for the tile DMAs issued above.)
         // (the order is STABLE -- by bin, then by slot: ranks handed out by an LDS atomic would be arrival orders, and the thread a bead
         // lands on decides the order in which the wall-reaction partials of a block are summed)
-        __shared__ unsigned s_hist[GD_BLOCK / 64][64];
-        s_hist[wid][lane] = 0;
+        // (one byte per (bin, wave) -- a wave holds at most 64 threads of a bin; lane b reads the eight counts of bin b as one 64-bit
+        // word.  GD_KBINS bins: the lists beyond 4 x (GD_KBINS - 2) near entries share the first one.)
+        constexpr unsigned GD_KBINS = 48u;
+        static_assert(GD_BLOCK / 64 == 8, "one byte per wave in a 64-bit word");
+        __shared__ unsigned long long s_hist8[GD_KBINS];
+        if (threadIdx.x < GD_KBINS) s_hist8[threadIdx.x] = 0ull;
         if (threadIdx.x >= 64 && threadIdx.x - 64 < sizeof(TileDesc) / 4) ((unsigned *)&s_tdesc)[threadIdx.x - 64] = ((const unsigned *)tdp)[threadIdx.x - 64];
-        unsigned bin = 63u;                                        // slots past N: last
-        if (slot < p.N) bin = 62u - min((unsigned)p.len_prev[(size_t)r * p.N + o_pre], 62u);
+        unsigned bin = GD_KBINS - 1u;                              // slots past N: last
+        if (slot < p.N) bin = (GD_KBINS - 2u) - min((unsigned)p.len_prev[(size_t)r * p.N + o_pre], GD_KBINS - 2u);
         // lanes of the wave in the same bin (six ballots), the thread's rank among them, their number
         unsigned long long same = ~0ull;
 #pragma unroll
@@ -1655,12 +1664,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 s_tile[t] = x;
             }
         }
-        if (rank_w == 0u) s_hist[wid][bin] = (unsigned)__popcll(same);
+        if (rank_w == 0u) ((unsigned char *)s_hist8)[bin * 8u + wid] = (unsigned char)__popcll(same);
         __syncthreads();
         // lane b stands for bin b: threads of the block in that bin, and those of them in the waves in front of this one
         unsigned incl = 0, before = 0;
-#pragma unroll
-        for (unsigned w = 0; w < GD_BLOCK / 64; w++) { const unsigned v = s_hist[w][lane]; incl += v; before += w < wid ? v : 0u; }
+        {
+            const unsigned long long v = lane < GD_KBINS ? s_hist8[lane] : 0ull;
+            const unsigned long long vb = v & ((1ull << (8u * wid)) - 1ull);      // the waves in front (wid < 8)
+            incl = __builtin_amdgcn_sad_u8((unsigned)v, 0u, __builtin_amdgcn_sad_u8((unsigned)(v >> 32), 0u, 0u));
+            before = __builtin_amdgcn_sad_u8((unsigned)vb, 0u, __builtin_amdgcn_sad_u8((unsigned)(vb >> 32), 0u, 0u));
+        }
         const unsigned own = incl;
         for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
         gt = rbase + blk * GD_BLOCK + (unsigned)__shfl((int)(incl - own + before), (int)bin, 64) + rank_w;
@@ -1964,14 +1977,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     unsigned long long c64 = min(cnt, p.W);
     unsigned cmax = cnt;
     for (int o = 32; o > 0; o >>= 1) { c64 += __shfl_xor(c64, o, 64); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o, 64)); }
-    if (lane == 0) { s_cnt[wid] = c64; s_max[wid] = cmax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        unsigned m = 0;
-        for (int w = 0; w < GD_BLOCK / 64; w++) { t += s_cnt[w]; m = max(m, s_max[w]); }
-        if (t) atomicAdd(&p.lcount[r], t);
-        if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
+    if (lane == 0) {
+        atomicAdd(&s_acc_cnt, c64); atomicMax(&s_acc_max, cmax);
+        __threadfence_block();
+        if (atomicAdd(&s_acc_done, 1u) == GD_BLOCK / 64 - 1u) {      // the last wave of the block to finish
+            __threadfence_block();
+            const unsigned long long t = atomicAdd(&s_acc_cnt, 0ull);
+            const unsigned m = atomicMax(&s_acc_max, 0u);
+            if (t) atomicAdd(&p.lcount[r], t);
+            if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
+        }
     }
     GD_FSTAMP(6);     // count
     GD_FSTAMP_END(p.dbg);

@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=1000, help="untimed steps with the timed phase's flags (the wall dynamics switch on here)")
     ap.add_argument("--beads", type=int, default=30000)
-    ap.add_argument("--replicas", type=int, default=128, help="replicas batched per GPU (64: -5%, 256: -7% on one MI355X)")
+    ap.add_argument("--replicas", type=int, default=128, help="replicas batched per GPU (64: -5 %%, 256: -7 %% on one MI355X)")
     ap.add_argument("--equil", type=int, default=20000,
                     help="untimed relaxation steps before warmup (SURVEY 8d cfg3: 20 000 from the random-walk start)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
