@@ -157,6 +157,14 @@ struct gd_system {
     bool bbox_valid = false;       // open boxes: bbox_enc[bbox_cur] holds the bounding box of the positions the last build sorted
     DevBuf<unsigned short> nbr16; DevBuf<TileDesc> tiles;
     DevBuf<float4> rec_x0; DevBuf<uint2> rec_mo; DevBuf<unsigned char> len_prev;
+    // Ragged rows of the tiled lists (BuildParams): per-wave row table, what every bead needed at the last build, the pool's cursor.
+    // nbr16 IS the pool: pool KiB = nbr16.n / 512 entries.
+    DevBuf<uint2> wtab; DevBuf<unsigned short> need_prev; DevBuf<unsigned> pool;
+    bool need_valid = false;       // need_prev describes the state about to be listed well enough to predict row widths from it
+    bool need_exact = false;       // ... and comes from a counting pass of these very positions (build_now's retry after an overflow)
+    float need_rv = 0; bool need_all_near = false;      // list radius / class mode need_prev was counted at
+    uint32_t pool_used = 0;        // KiB the last filling pass took (its cursor's final value; beyond the pool's size when that was full)
+    uint32_t pool_used_exact = 0;  // 1: that pass was exact (no slack in it: the next, predicted, one takes an eighth + 2 KiB per wave more)
     DevBuf<float> bbox;
     DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<int4> chain;
     float mob_uniform = -1.f;
@@ -266,6 +274,7 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
          s->lcount_d.resize(s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess &&
+         s->wtab.resize(RNp / 64) == hipSuccess && s->need_prev.resize((size_t)s->R * s->N) == hipSuccess && s->pool.resize(4) == hipSuccess &&
          s->lo.resize(RN) == hipSuccess;
     s->lo_valid = ok;      // (positions and residuals all zero)
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
@@ -325,6 +334,7 @@ extern "C" int gd_set_positions(gd_system *s, const double *xyz)
     gd_launch_identity(s->orig[s->ocur].p, s->slot_of.p, s->N, s->Np, s->R, s->stream);
     HIPCHK(hipStreamSynchronize(s->stream));
     s->list_valid = false; s->state_serial++; s->w_packed = false; s->bbox_valid = false;
+    s->need_valid = false;      // (positions from the caller: what the beads needed before says nothing about their lists now)
     return GD_OK;
 }
 
@@ -761,7 +771,7 @@ static void fill_common(gd_system *s, StepParams &p)
     for (int k = 0; k < 3; k++) { p.box[k] = (float)s->box[k]; p.inv_box[k] = s->box[k] > 0 ? (float)(1.0 / s->box[k]) : 0.f; }
     p.pos_in = s->pos[s->pcur].p; p.pos_out = s->pos[s->pcur ^ 1].p; p.xb = s->xb.p; p.orig = s->orig[s->ocur].p;
     p.ab = s->ab.p; p.mob = s->mobs.p; p.bendE = s->bendE.p; p.mob_uniform = s->mob_uniform; p.WB = s->WB;
-    p.nbr = s->nbr.p; p.nbr16 = s->nbr16.p; p.tiles = s->tiles.p; p.tiled = s->list_tiled ? 1 : 0; p.packed_ab = s->packed_ab ? 1 : 0;
+    p.nbr = s->nbr.p; p.nbr16 = s->nbr16.p; p.wtab = s->wtab.p; p.tiles = s->tiles.p; p.tiled = s->list_tiled ? 1 : 0; p.packed_ab = s->packed_ab ? 1 : 0;
     p.cpb = s->cpb; p.tile_cap = s->list_tiled ? s->list_tile_cap : s->tile_cap;   // as at the build of the list in use
     p.pk = (s->has_pair && s->pair.p_a == 2 && s->pair.q_a == 3 && s->pair.p_b == 8 && s->pair.q_b == 3) ? (s->pair.mix ? 1 : 2) : 0;
     p.meta = s->meta.p; p.rec_x0 = s->rec_x0.p; p.rec_mo = s->rec_mo.p; p.W = s->list_W; p.badj = s->badj.p; p.chain = s->chain.p;
@@ -819,13 +829,11 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     if (with_list) {
         if (s->W == 0) s->W = 96;
         s->W = (s->W + GD_UNROLL - 1) & ~(GD_UNROLL - 1);
-        const size_t need = (size_t)s->W * s->R * s->Np;   // entries; chunked wave-interleaved layout (k_step)
-        // (grown on demand -- with an eighth to spare once the rows are long: the exact sizing of a dense start ends in a few builds
-        // that each ask for a handful of entries more, and every one of them used to free and allocate the whole 18 GB again --
-        // given back when a dense transient has passed)
+        // generic lists: uniform rows of W entries (chunked wave-interleaved layout, k_step), grown on demand -- with an eighth to spare
+        // once the rows are long -- and given back when a dense transient has passed.  Tiled lists: ragged rows from a pool, below.
+        const size_t need = (size_t)s->W * s->R * s->Np;
         const size_t grow = s->W >= 512 ? need + need / 8 : need;
-        if (tiled) { if (s->nbr16.n < need || s->nbr16.n > 4 * need) HIPCHK(s->nbr16.resize(grow, false)); }
-        else if (s->nbr.n < need || s->nbr.n > 4 * need) HIPCHK(s->nbr.resize(grow, false));
+        if (!tiled && (s->nbr.n < need || s->nbr.n > 4 * need)) HIPCHK(s->nbr.resize(grow, false));
         s->list_W = s->W;
     }
     BuildParams b;
@@ -856,7 +864,40 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.w_valid = (s->packed_ab && s->w_packed) ? 1 : 0;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
-    gd_launch_build(b, s->stream);
+    b.wtab = s->wtab.p; b.need_prev = s->need_prev.p; b.pool = s->pool.p;
+    if (tiled) {
+        // Ragged rows (BuildParams): every k_step wave's rows are as wide as its longest list.  A WARM build predicts the widths from
+        // what each bead needed at the build before and takes the rows from the pool as it goes; a COLD one -- no history (first
+        // build, positions from the caller, a rolled-back overflow), another list radius or class mode -- counts first: the chain
+        // with the counting pass of k_fill, the pool sized from its total, then the filling pass with exact widths.
+        const size_t waves = (size_t)s->R * s->Np / 64;
+        const bool cold = !s->need_valid || s->need_all_near != s->all_near || !(s->need_rv > 0) || std::fabs(rv / s->need_rv - 1.f) > 0.02f;
+        auto pool_kib = [&]() { return (size_t)(s->nbr16.n / 512); };
+        auto size_pool = [&](size_t want_kib) -> hipError_t {      // (not preserved: the list in it is about to be rebuilt)
+            if (pool_kib() >= want_kib && pool_kib() <= 2 * want_kib + 4 * waves) return hipSuccess;
+            return s->nbr16.resize((want_kib + want_kib / 16 + waves) * 512, false);
+        };
+        if (cold) {
+            b.exact = 1; b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
+            gd_launch_build(b, s->stream, 1);
+            unsigned pw[2] = {0u, 0u};
+            HIPCHK(hipMemcpyAsync(pw, s->pool.p, sizeof pw, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(size_pool(std::max<size_t>(pw[1], waves)));
+            b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
+            gd_launch_build(b, s->stream, 2);
+            s->pool_used = pw[1]; s->pool_used_exact = 1;
+        } else {
+            // (the pool's use is read back with every chunk; the builds in between grow with the lists: an eighth to spare on top of
+            // the slack the predicted widths carry themselves -- an eighth + a chunk per class and wave over an exact pass's total)
+            const size_t used = std::max<size_t>(s->pool_used, waves);
+            HIPCHK(size_pool(s->pool_used_exact ? used + used / 4 + 3 * waves : used + used / 8 + waves));
+            b.exact = 0; b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
+            gd_launch_build(b, s->stream, 0);
+            s->pool_used_exact = 0;
+        }
+        s->need_valid = true; s->need_rv = rv; s->need_all_near = s->all_near;
+    } else gd_launch_build(b, s->stream, 0);
     s->bbox_cur ^= 1; s->bbox_valid = tiled;      // (the box of the positions this build sorted, reduced by k_tiles: the next build's grid)
     s->list_tiled = tiled; s->list_tile_cap = s->tile_cap;
     s->w_packed = s->packed_ab;
@@ -871,7 +912,10 @@ static int read_flags(gd_system *s, std::vector<unsigned> &f)
     HIPCHK(hipGetLastError());
     f.resize((size_t)s->R * GD_NFLAGS);
     HIPCHK(hipMemcpyAsync(f.data(), s->flags.p, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+    unsigned used = 0;
+    HIPCHK(hipMemcpyAsync(&used, s->pool.p, sizeof used, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->list_tiled && used > 0) s->pool_used = used;
     return GD_OK;
 }
 static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (size_t)s->R * GD_NFLAGS * sizeof(unsigned), s->stream)); return GD_OK; }
@@ -891,12 +935,11 @@ static unsigned pick_tile_cap(unsigned need)
 }
 
 // A build that meets a dense state -- the spline-refined start of the pipeline is a globule in which some beads have 1 500
-// neighbours inside the default list radius -- sizes every row of the handle for its longest list (rows are uniform).  While
-// that fits a sixteenth of the device memory at two bytes per entry nothing is done (128 x 30 000 beads x 2 340 entries = 18 GB
-// of 288; a quarter of the memory -- rows of 8 688 entries, interval 3 instead of 1 -- was measured on the 128-file pipeline:
-// the same 20 s of gd_run, the work of such a state is its pairs, not its builds); beyond it the list width is narrowed so that the longest list, which grows with the cube of the radius, fits (at
-// least a skin of 0.15 x cutoff), and class_skin returns to the width it left once the longest list, scaled back, fits again.
-// Not with a caller-chosen skin.
+// neighbours inside the default list radius.  Tiled lists have ragged rows: the pool holds what the waves need, not the longest list
+// times every bead (uniform rows took 18-20 GB at 128 x 30 000 beads there; the pool a fifth of it), so this guard is a safety net:
+// only when the rows exceed a sixteenth of the device memory is the list width narrowed so that they fit (lists grow with the cube of
+// the radius; at least a skin of 0.15 x cutoff), and class_skin returns to the width it left once the longest list, scaled back, fits
+// again.  Not with a caller-chosen skin.
 static void dense_guard(gd_system *s, unsigned need_w)
 {
     if (s->skin_fixed || need_w <= 512u || !(s->rv > 0)) return;
@@ -904,19 +947,22 @@ static void dense_guard(gd_system *s, unsigned need_w)
     if (!(cut > 0)) return;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
-    // rows of the width the build asked for: two bytes per entry while a tiled row can hold them, four on the generic path
+    // what the rows of the build take: tiled lists the pool's use (ragged rows: the sum of what the waves need), generic lists uniform
+    // rows of the longest list at four bytes per entry
     const double rows = (double)s->R * (double)s->Np, budget_b = (double)(total_b / 16);
-    if ((double)need_w * (need_w <= GD_TILED_MAX_W ? 2.0 : 4.0) * rows <= budget_b) return;      // (fits: also when only the tiled record is too small for it)
-    const double w_budget = std::min((double)GD_TILED_MAX_W, budget_b / (2.0 * rows));
-    s->dense_budget = (uint32_t)std::max(64.0, w_budget);
+    const double bytes = s->list_tiled ? 1024.0 * (double)s->pool_used : (double)need_w * 4.0 * rows;
+    if (bytes <= budget_b) return;
+    const double shrink = 0.9 * budget_b / bytes;                 // lists grow with the cube of the radius
+    s->dense_budget = (uint32_t)std::max(64.0, (double)need_w * budget_b / bytes);
     const double sc = s->rv / cut - s->skin;                       // bead-scale part of the radius the build used
-    const double r_new = s->rv * std::cbrt(0.9 * w_budget / (double)need_w);
+    const double r_new = s->rv * std::cbrt(shrink);
     const double skin_new = std::max(0.15, r_new / cut - sc);
     if (skin_new < s->skin - 1e-9) {
         if (!(s->skin_dense_from > 0)) s->skin_dense_from = s->skin;
-        s->skin = skin_new; s->skin_next = 0; s->K = std::max(1u, std::min(s->K, 4u)); s->a2_ema = 0;
-        s->W = std::max(64u, s->dense_budget & ~7u);      // (the narrowed list is predicted at 0.9 of the budget; a miss is one more exactly sized build)
-        if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state (longest list %u): skin %.3f\n", need_w, skin_new);
+        s->skin = skin_new; s->skin_next = 0; s->a2_ema = 0;
+        if (s->adapt) s->K = std::max(1u, std::min(s->K, 4u));      // (a caller-fixed interval stays the caller's)
+        if (!s->list_tiled) s->W = std::max(64u, s->dense_budget & ~7u);      // (the narrowed list is predicted at 0.9 of the budget; a miss is one more exactly sized build)
+        if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state (longest list %u, rows %.1f GB): skin %.3f\n", need_w, bytes / 1e9, skin_new);
     }
 }
 
@@ -968,12 +1014,14 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         else { s->tiled_ok = false; s->tiled_off = 1; }     // too dense for one tile: generic path (retried later with back-off)
     }
     if (over) {
-        // The overflowing build has counted the longest list exactly (a row keeps counting past its width): the next build gets
-        // that width with 6 % to spare -- not a doubling, and not beyond what a tiled row can hold while the need still fits one
-        // (a width beyond GD_TILED_MAX_W sends the handle to generic lists at 4 bytes per entry: the 29 GB allocation of round 3).
-        unsigned w = need_w + need_w / 16 + 8;
-        if (need_w <= GD_TILED_MAX_W) w = std::min(w, GD_TILED_MAX_W);
-        s->W = std::max(w, s->W + 8);
+        // Tiled lists (ragged rows): a bead outgrew the rows predicted for its wave, or the pool was full -- the next build is a cold
+        // one, it counts before it fills.  Generic lists (uniform rows): the overflowing build has counted the longest list exactly (a
+        // row keeps counting past its width): the next build gets that width with 6 % to spare.
+        s->need_valid = false;
+        if (!s->list_tiled) {
+            unsigned w = need_w + need_w / 16 + 8;
+            s->W = std::max(w, s->W + 8);
+        }
         if (class_over) {
             // a class beyond its field of the tiled record: single-class lists while that is the far class; a near class beyond
             // 8 184 entries is beyond tiled rows
@@ -983,10 +1031,12 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         dense_guard(s, need_w);
     }
     else if (!tover && need_w > 0) {
+        if (s->list_tiled && (size_t)s->pool_used * 1024u > ((size_t)4 << 30)) dense_guard(s, need_w);      // (rows of several GB: within the budget?)
         if (s->all_near && need_w <= GD_TILED_MAX_FAR) s->all_near = false;      // (no far class can overflow its field any more; from the next build)
-        // the longest list is reported by every build: give the row width back when a dense transient has passed
+        // the longest list is reported by every build: generic lists give the row width back when a dense transient has passed
         const unsigned want_w = std::max(64u, (need_w + need_w / 4 + 16 + GD_UNROLL - 1) & ~(GD_UNROLL - 1));
-        if (2 * want_w <= s->W) s->W = want_w;       // (takes effect at the next build; the list in use keeps list_W)
+        if (!s->list_tiled && 2 * want_w <= s->W) s->W = want_w;       // (takes effect at the next build; the list in use keeps list_W)
+        else if (s->list_tiled && s->W > GD_TILED_MAX_W && need_w <= GD_TILED_MAX_NEAR) s->W = 96;      // (a near class beyond the tiled record has passed)
     }
     if (tover && dev_env("GDYN_DEBUG")) {
         std::vector<GridP> gp(s->R);
@@ -1382,7 +1432,8 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         HIPCHK(hipGetLastError());
         {
             const size_t nf = f.size() * sizeof(unsigned), nc = s->R * sizeof(DevCtx), nl = s->R * sizeof(unsigned long long), nd = s->R * sizeof(float);
-            if (!s->h_chunk) HIPCHK(hipHostMalloc((void **)&s->h_chunk, nf + nc + nl + nd, hipHostMallocDefault));
+            if (!s->h_chunk) HIPCHK(hipHostMalloc((void **)&s->h_chunk, nf + nc + nl + nd + 16, hipHostMallocDefault));
+            HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc + nl + nd, s->pool.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));      // the row pool's use
             HIPCHK(hipMemcpyAsync(s->h_chunk, s->flags.p, nf, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(s->h_chunk + nf, s->ctx[s->ccur].p, nc, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc, s->lcount_d.p, nl, hipMemcpyDeviceToHost, s->stream));
@@ -1394,6 +1445,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             memcpy(f.data(), s->h_chunk, nf); memcpy(ctx_new.data(), s->h_chunk + nf, nc); memcpy(s->lcount.data(), s->h_chunk + nf + nc, nl);
             last_dmax2 = 0;
             for (uint32_t r = 0; r < s->R; r++) { float d2; memcpy(&d2, s->h_chunk + nf + nc + nl + r * sizeof(float), 4); last_dmax2 = std::max(last_dmax2, d2); }
+            { unsigned used = 0; memcpy(&used, s->h_chunk + nf + nc + nl + nd, 4); if (s->list_tiled && used > 0) s->pool_used = used; }
         }
         bool violated = false; float maxd2 = 0;
         for (uint32_t r = 0; r < s->R; r++) {
@@ -1558,7 +1610,7 @@ static int search_device(gd_system *s, uint32_t r0, uint32_t nrep, double dcut, 
         PairsP q;
         memset(&q, 0, sizeof q);
         q.pos = s->pos[s->pcur].p; q.x0 = s->list_tiled ? s->rec_x0.p : s->xb.p; q.rec_mo = s->rec_mo.p; q.meta = s->meta.p;
-        q.orig = s->orig[s->ocur].p; q.nbr = s->nbr.p; q.nbr16 = s->nbr16.p; q.tiles = s->tiles.p;
+        q.orig = s->orig[s->ocur].p; q.nbr = s->nbr.p; q.nbr16 = s->nbr16.p; q.tiles = s->tiles.p; q.wtab = s->wtab.p;
         q.N = s->N; q.Np = s->Np; q.nblk = s->nblk; q.r = r0; q.nrep = nrep; q.W = s->list_W;
         q.tiled = s->list_tiled ? 1 : 0; q.s16 = (s->list_tiled && s->list_tile_cap < 4096u) ? 1 : 0;
         q.periodic = s->box_kind == GD_BOX_PERIODIC;

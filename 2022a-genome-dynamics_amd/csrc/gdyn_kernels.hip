@@ -409,7 +409,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     // (tiled path: the thread's records sit at rbase + blk * GD_BLOCK + tid -- the balanced thread order of the build)
     // (its wave index is wave-uniform: chunk addresses are a scalar base + lane, no per-lane 64-bit multiplies)
     const size_t gw6 = (rbase + blk * GD_BLOCK) / 64 + (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)wid);
-    const unsigned NCL = TILED ? p.W / 8 : p.W / 4, NCB = p.WB / 4;
+    // (tiled lists: ragged rows -- first KiB and chunks per lane of this wave's rows, one scalar load)
+    const uint2 wrow = TILED ? p.wtab[gw6] : make_uint2(0u, 0u);
+    const unsigned NCL = TILED ? wrow.y : p.W / 4, NCB = p.WB / 4;
     uint2 mo = make_uint2(0u, 0u);
     float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
     uint4 adj0 = make_uint4(0, 0, 0, 0), qa = adj0, qb = adj0;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
 #endif
         {
         adj0 = ((const uint4 *)p.badj)[gw6 * NCB * 64 + lane];
-        qa = nt_load((const uint4 *)p.nbr16 + gw6 * NCL * 64 + lane);
+        qa = nt_load((const uint4 *)p.nbr16 + (size_t)wrow.x * 64 + lane);
         }
         GD_STAMP(8);      // per-bead loads issued
     } else {
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
     unsigned slot = blk * GD_BLOCK + tid;
     bool valid = slot < p.N;
     size_t g = rbase + slot;
-    const uint4 *__restrict__ lst = TILED ? (const uint4 *)p.nbr16 + gw6 * NCL * 64 + lane : (const uint4 *)p.nbr + (size_t)(g >> 6) * NCL * 64 + (g & 63);
+    const uint4 *__restrict__ lst = TILED ? (const uint4 *)p.nbr16 + (size_t)wrow.x * 64 + lane : (const uint4 *)p.nbr + (size_t)(g >> 6) * NCL * 64 + (g & 63);
     const uint4 *__restrict__ adj = (const uint4 *)p.badj + (TILED ? gw6 * NCB * 64 + lane : (size_t)(g >> 6) * NCB * 64 + (g & 63));
     float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f), x0 = xi4;
     unsigned meta = 0, oid = 0;
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
             // (a second batch of look-ahead bought nothing and costs the registers of one occupancy step)
             // (tiled: chunk c of the thread = wave base + c KiB + lane x 16 bytes -- a scalar base and a 32-bit offset, no per-lane
             // 64-bit pointer lives across the loop)
-            const char *lst_w = (const char *)((const uint4 *)p.nbr16 + gw6 * NCL * 64);
+            const char *lst_w = (const char *)((const uint4 *)p.nbr16 + (size_t)wrow.x * 64);
 #ifdef GD_REPLAY
             float4 rp_x = make_float4(xi.x + 0.11f, xi.y - 0.07f, xi.z + 0.05f, xi4.w);      // (RP_ALU: the neighbour every entry stands for)
             auto chunk = [&](unsigned c) -> uint4 {
@@ -1281,6 +1283,7 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
     unsigned t0 = blockIdx.y * GD_SCAN_TILE;
     if (blockIdx.y == 0 && tid == 1023) {      // the per-build words of the replica start over (the last wave: off the path of the scan)
         p.lcount[r] = 0ull;
+        if (r == 0 && p.pool) { p.pool[0] = 0u; p.pool[1] = 0u; }      // the row pool's cursor and the counting pass's total (BuildParams)
         p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
         if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
     }
@@ -1578,9 +1581,12 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
 
 // Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
 // TILED: candidates are read from the block's LDS tile and list entries are tile indices.
-template <bool PERIODIC, bool TILED, bool S16>
+// COUNT (tiled lists): the counting pass of an exact build -- the sort, the tile and the distance tests of the filling pass, no rows,
+// no re-map: every bead's need goes to need_prev, the KiB the rows of the block's waves need to pool[1] (BuildParams).
+template <bool PERIODIC, bool TILED, bool S16, bool COUNT = false>
 __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
+    static_assert(TILED || !COUNT, "the counting pass belongs to the ragged rows of the tiled lists");
     GD_FSTAMP_BEGIN();
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     // block totals (list entries, longest list): accumulated by LDS atomics as the waves finish; the last one to finish hands them on --
@@ -1588,10 +1594,13 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     // three blocks fit a CU only up to 704 bytes of it -- LDS is granted in 1 280-byte granules; tools/kregs.py shows the figure.)
     __shared__ unsigned long long s_acc_cnt;
     __shared__ unsigned s_acc_max, s_acc_done;
+    // ragged rows: chunks per lane and first KiB of the rows of each of the block's eight k_step waves
+    __shared__ unsigned s_wn[GD_BLOCK / 64], s_woff[GD_BLOCK / 64];
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_acc_cnt = 0ull; s_acc_max = 0u; s_acc_done = 0u; }
+    if (threadIdx.x < GD_BLOCK / 64) { s_wn[threadIdx.x] = 0u; s_woff[threadIdx.x] = 0u; }
     if (!TILED) __syncthreads();      // (the tiled path has its barriers below)
     const size_t rbase = (size_t)r * p.Np;
     const unsigned slot = blk * GD_BLOCK + threadIdx.x;
@@ -1678,22 +1687,56 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
         gt = rbase + blk * GD_BLOCK + (unsigned)__shfl((int)(incl - own + before), (int)bin, 64) + rank_w;
     }
+    // Ragged rows: the k_step wave a bead goes to (wk) gets rows as wide as the longest PREDICTED list among its 64 beads -- what the
+    // bead needed at the build before, plus an eighth and a chunk per class (exact builds: what the counting pass has just
+    // counted, nothing to spare); at least one chunk, so that k_step's unconditional first chunk load stays inside the pool.
+    const unsigned wk = TILED ? ((unsigned)(gt - rbase) - blk * GD_BLOCK) >> 6 : 0u;
+    if (TILED && !COUNT) {
+        unsigned want = 1u;
+        if (slot < p.N) {
+            const unsigned q = p.need_prev[(size_t)r * p.N + o_pre];
+            unsigned pn = q & 1023u, pf = q >> 10;
+            if (!p.exact) { pn += max(1u, pn >> 3); pf += max(1u, pf >> 3); }
+            want = max(min(pn, GD_TILED_MAX_NEAR / 8u) + min(pf, GD_TILED_MAX_FAR / 8u), 1u);
+        }
+        atomicMax(&s_wn[wk], want);
+        __syncthreads();
+        if (threadIdx.x < GD_BLOCK / 64) {      // eight lanes of wave 0: prefix of the widths, ONE atomic on the pool's cursor per block
+            const unsigned nc = s_wn[threadIdx.x];
+            unsigned incl = nc;
+            for (int o = 1; o < GD_BLOCK / 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+            const unsigned total = __shfl(incl, GD_BLOCK / 64 - 1, 64);
+            unsigned base = 0;
+            if (threadIdx.x == GD_BLOCK / 64 - 1) base = atomicAdd(&p.pool[0], total);
+            base = __shfl(base, GD_BLOCK / 64 - 1, 64);
+            // (a pool that is full: flagged like a row overflow, the rows of this block get no chunks -- every bead of it then counts
+            // as overflowed -- and k_step's first chunk load reads the pool's first KiB)
+            const bool fits = base <= p.pool_cap && total <= p.pool_cap - base;
+            if (!fits && threadIdx.x == 0 && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);
+            const unsigned off = fits ? base + incl - nc : 0u;
+            p.wtab[(rbase + (size_t)blk * GD_BLOCK) / 64 + threadIdx.x] = make_uint2(off, fits ? nc : 0u);
+            s_woff[threadIdx.x] = off; s_wn[threadIdx.x] = fits ? nc : 0u;
+        }
+        // (the cursor's answer is needed behind the re-map of the bonded topology below: a barrier there, not here)
+    }
     GD_FSTAMP(0);     // staging + barrier
     unsigned cnt = 0;
+    unsigned o = 0, deg = 0;
+    const unsigned nr_tile = TILED ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_td.nranges) : 0u;      // (merged ranges in use: three, typically)
+    auto to_local = [&](unsigned ps, unsigned &idx) -> bool {   // slot -> tile index
+        for (unsigned k = 0; k < nr_tile; k++) {
+            const unsigned d = ps - s_td.start[k];
+            if (d < s_td.len[k]) { idx = s_td.base[k] + d; return true; }
+        }
+        return false;
+    };
+    const size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
     if (slot < p.N) {
-        unsigned listlen = 0, nAq = 0, nB = 0;
-        const unsigned o = p.orig_out[g];
+        o = p.orig_out[g];
+        deg = p.bdeg_o[o];
+    }
+    if (!COUNT && slot < p.N) {
         const unsigned *so = p.slot_of + (size_t)r * p.N;
-        const unsigned nr_tile = TILED ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_td.nranges) : 0u;      // (merged ranges in use: three, typically)
-        auto to_local = [&](unsigned ps, unsigned &idx) -> bool {   // slot -> tile index
-            for (unsigned k = 0; k < nr_tile; k++) {
-                const unsigned d = ps - s_td.start[k];
-                if (d < s_td.len[k]) { idx = s_td.base[k] + d; return true; }
-            }
-            return false;
-        };
-        const unsigned deg = p.bdeg_o[o];
-        const size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
         uint4 *__restrict__ adjw = (uint4 *)p.badj + (size_t)(gw >> 6) * (p.WB / 4) * 64 + (gw & 63);
         // one 16-byte adjacency chunk per round: its four gathers (entry by bead, then slot by partner) are in flight
         // together and the chunk is written with one store
@@ -1723,7 +1766,11 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             };
             p.chain[g] = make_int4(conv(c.x), conv(c.y), conv(c.z), conv(c.w));
         }
-        GD_FSTAMP(1);     // bond / chain re-map
+    }
+    GD_FSTAMP(1);     // bond / chain re-map
+    if (TILED && !COUNT) __syncthreads();      // the rows of the block's waves have their place (s_woff, s_wn)
+    if (slot < p.N) {
+        unsigned listlen = 0, nAq = 0, nB = 0;
         if (!(p.nbr || p.nbr16)) {      // (a sort without lists: the counter of the bead's cell still goes back to zero, see below)
             const GridP gp = p.grid[r];
             int cx, cy, cz;
@@ -1748,8 +1795,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // list writer: entries go straight into the wave-interleaved 16-byte chunk layout k_step
             // reads (8 x u16 tiled, 4 x u32 generic); a bead's 8 (4) consecutive entries share one chunk.
             constexpr unsigned PER = TILED ? 8u : 4u;
-            const unsigned NC = p.W / PER;
-            uint4 *__restrict__ lst = (TILED ? (uint4 *)p.nbr16 : (uint4 *)p.nbr) + (size_t)(gw >> 6) * NC * 64 + (gw & 63);
+            // (tiled: the rows of the thread's k_step wave -- NC chunks per lane from KiB s_woff[wk] of the pool; generic: uniform rows)
+            const unsigned NC = TILED ? s_wn[wk] : p.W / PER;
+            uint4 *__restrict__ lst = TILED ? (uint4 *)p.nbr16 + ((size_t)s_woff[wk] * 64 + (gw & 63)) : (uint4 *)p.nbr + (size_t)(gw >> 6) * NC * 64 + (gw & 63);
             // the 16-byte chunk under construction lives in four registers (an LDS staging slot per thread would cost
             // the 8 KB that separate two from three resident blocks per CU); every PER-th entry the finished chunk
             // goes out as one 16-byte global store (2-byte scattered global stores were 25% of the build)
@@ -1770,7 +1818,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 }
                 cnt++;
                 if (cnt % PER == 0) {
-                    if (cnt + cntB <= p.W) {
+                    if (cnt / PER <= NC) {      // (inside the row; a list that outgrows its row is flagged below, its chunk rolled back)
                         flush();                               // (only if a second chunk fills before the next flush point)
                         p0 = w0; p1 = w1; p2 = w2; p3 = w3; pend = cnt / PER;
                     }
@@ -1780,7 +1828,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 b0 = __builtin_amdgcn_alignbit(b1, b0, 16); b1 = __builtin_amdgcn_alignbit(b2, b1, 16);
                 b2 = __builtin_amdgcn_alignbit(b3, b2, 16); b3 = __builtin_amdgcn_alignbit(j, b3, 16);
                 cntB++;
-                if (cntB % 8u == 0) { if (((cnt + 7u) & ~7u) + cntB <= p.W) lst[(size_t)(NC - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3); }
+                if (cntB % 8u == 0) { if (cntB / 8u <= NC) lst[(size_t)(NC - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3); }
             };
             if (TILED && PERIODIC) {
                 // periodic tile = whole rows: for each of the 9 wrapped (dz,dy) rows the x-window cx-1..cx+1 is one slot interval, or
@@ -1834,6 +1882,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             mn &= m; m ^= mn;                                 // near class, far class
                             // (lowest set bit first: find-first-bit, then clear it with m & (m - 1) -- three instructions less per entry than
                             // isolating the highest bit; the order of a bead's entries is immaterial)
+                            if (COUNT) { cnt += (unsigned)__popc(mn); cntB += (unsigned)__popc(m); mn = 0u; m = 0u; }
                             while (mn) {
                                 const unsigned bit = (unsigned)__builtin_ctz(mn);
                                 mn &= mn - 1u;
@@ -1896,6 +1945,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             GD_FSTAMP(3);     // distance tests
                             // (lowest set bit first: find-first-bit, then clear it with m & (m - 1) -- three instructions less per entry than
                             // isolating the highest bit; the order of a bead's entries is immaterial)
+                            if (COUNT) { cnt += (unsigned)__popc(mn); cntB += (unsigned)__popc(m); mn = 0u; m = 0u; }
                             while (mn) {
                                 GD_FCOUNT(9);
                                 const unsigned bit = (unsigned)__builtin_ctz(mn);
@@ -1949,21 +1999,33 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // class beyond that does not fit it even when the row is wide enough for the sum -- flagged like a row overflow, bit 1 on
             // top (the host then builds single-class lists, or generic ones beyond 8 184 entries, until the dense transient has passed)
             const bool class_over = TILED && (needA > GD_TILED_MAX_NEAR || needB > GD_TILED_MAX_FAR);
-            if ((needw > p.W || (TILED && needw > GD_TILED_MAX_W) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
+            // (a counting pass has no rows to overflow: only a class beyond its field counts)
+            const unsigned Wrow = NC * PER;
+            if (((!COUNT && needw > Wrow) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
                 atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], class_over ? 3u : 1u);
                 atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], needw);
             }
-            listlen = min(found, p.W);
+            if (TILED) {
+                // what this bead needed, for the rows of the next build (or of the filling pass behind this counting pass); the
+                // k_step wave it goes to needs the sum for its longest list
+                const unsigned na8 = min(needA / 8u, GD_TILED_MAX_NEAR / 8u), nb8 = min(needB / 8u, GD_TILED_MAX_FAR / 8u);
+                p.need_prev[(size_t)r * p.N + o] = (unsigned short)(na8 | (nb8 << 10));
+                if (COUNT) atomicMax(&s_wn[wk], max(na8 + nb8, 1u));
+            }
+            listlen = min(found, Wrow);
             nAq = min((cnt + 3u) / 4u, GD_TILED_MAX_NEAR / 4u);            // near entries in fours (the record's count; chunks are still written whole)
-            while (cnt % GD_UNROLL) push(self);
-            flush();
-            if (TILED) while (cntB % GD_UNROLL) push_far(self);
+            if (!COUNT) {
+                while (cnt % GD_UNROLL) push(self);
+                flush();
+                if (TILED) while (cntB % GD_UNROLL) push_far(self);
+            }
             // (an overflowed list is flagged and its chunk rolled back; the chunk counts still have to stay inside the row)
             nAq = min(nAq, 2u * NC); nB = min(min(cntB / GD_UNROLL, GD_TILED_MAX_FAR / GD_UNROLL), NC - (nAq + 1u) / 2u);
             cnt = found;
         }
         const unsigned meta = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
-        if (TILED) {
+        if (COUNT) { }      // (records, sort keys and lists are the filling pass's)
+        else if (TILED) {
             const float4 xb = rpos[slot];
             p.rec_x0[gt] = make_float4(xb.x, xb.y, xb.z, __uint_as_float(slot - blk * GD_BLOCK));
             // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | near entries / 4 << 21, bead id | far chunks << 26
@@ -1972,9 +2034,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             p.len_prev[(size_t)r * p.N + o] = (unsigned char)min(nAq, 255u);       // (the near class is what most steps run over)
         } else p.meta[g] = meta;
     }
-    if (TILED && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
+    if (TILED && !COUNT && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
     GD_FSTAMP(5);     // padding, meta
-    unsigned long long c64 = min(cnt, p.W);
+    unsigned long long c64 = cnt;
     unsigned cmax = cnt;
     for (int o = 32; o > 0; o >>= 1) { c64 += __shfl_xor(c64, o, 64); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o, 64)); }
     if (lane == 0) {
@@ -1984,7 +2046,12 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             __threadfence_block();
             const unsigned long long t = atomicAdd(&s_acc_cnt, 0ull);
             const unsigned m = atomicMax(&s_acc_max, 0u);
-            if (t) atomicAdd(&p.lcount[r], t);
+            if (COUNT) {      // KiB the rows of this block's eight waves need (a wave without a bead: one chunk, as in the filling pass)
+                unsigned kib = 0;
+                for (unsigned w = 0; w < GD_BLOCK / 64; w++) kib += max(atomicMax(&s_wn[w], 0u), 1u);
+                atomicAdd(&p.pool[1], kib);
+            }
+            if (t && !COUNT) atomicAdd(&p.lcount[r], t);
             if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
         }
     }
@@ -1994,31 +2061,38 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 
 #undef s_td
 
-void gd_launch_build(const BuildParams &p, hipStream_t st)
+void gd_launch_build(const BuildParams &p, hipStream_t st, int what)
 {
     const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk);
     // five launches: count + rank (the grid laid by every block itself) | scan | scatter (+ the box of the next build's grid) | tile
     // descriptors | fill (+ the cell counters back to zero).  An open box without a bounding box from the build before (the first build of a handle, positions set by
-    // the caller): k_bbox and k_gridp in front.
-    if (p.periodic) hipLaunchKernelGGL((k_bin<true, true>), grid, block, 0, st, p);
-    else if (p.warm) hipLaunchKernelGGL((k_bin<false, true>), grid, block, 0, st, p);
-    else {
-        hipLaunchKernelGGL(k_bbox, dim3(p.R * ((p.nblk + 3u) / 4u)), block, 0, st, p);
-        hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(GD_GRIDP_THREADS), 0, st, p);
-        hipLaunchKernelGGL((k_bin<false, false>), grid, block, 0, st, p);
+    // the caller): k_bbox and k_gridp in front.  what = 2: the filling pass alone, behind a chain that ended in the counting pass (what = 1).
+    if (what != 2) {
+        if (p.periodic) hipLaunchKernelGGL((k_bin<true, true>), grid, block, 0, st, p);
+        else if (p.warm) hipLaunchKernelGGL((k_bin<false, true>), grid, block, 0, st, p);
+        else {
+            hipLaunchKernelGGL(k_bbox, dim3(p.R * ((p.nblk + 3u) / 4u)), block, 0, st, p);
+            hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(GD_GRIDP_THREADS), 0, st, p);
+            hipLaunchKernelGGL((k_bin<false, false>), grid, block, 0, st, p);
+        }
+        hipLaunchKernelGGL(k_scan, dim3(p.R, std::max(1u, p.scan_segments)), dim3(1024), 0, st, p);
+        if (p.periodic) { hipLaunchKernelGGL(k_members<true>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p); }
+        else { hipLaunchKernelGGL(k_members<false>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p); }
+        if (p.tiled && p.periodic) hipLaunchKernelGGL(k_tiles<true>, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
+        else if (p.tiled) hipLaunchKernelGGL(k_tiles<false>, dim3((p.R * p.nblk + 63) / 64 + p.R), dim3(64), 0, st, p);
     }
-    hipLaunchKernelGGL(k_scan, dim3(p.R, std::max(1u, p.scan_segments)), dim3(1024), 0, st, p);
-    if (p.periodic) { hipLaunchKernelGGL(k_members<true>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p); }
-    else { hipLaunchKernelGGL(k_members<false>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p); }
-    if (p.tiled && p.periodic) hipLaunchKernelGGL(k_tiles<true>, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
-    else if (p.tiled) hipLaunchKernelGGL(k_tiles<false>, dim3((p.R * p.nblk + 63) / 64 + p.R), dim3(64), 0, st, p);
     if (p.tiled) {
         const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
-        if (p.periodic) {
-            if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p);
-            else hipLaunchKernelGGL((k_fill<true, true, false>), gridx, block, lds, st, p);
-        } else if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<false, true, true>), gridx, block, lds, st, p);    // byte-offset entries, as k_step expects
-        else hipLaunchKernelGGL((k_fill<false, true, false>), gridx, block, lds, st, p);
+        const bool s16 = p.tile_cap < 4096u;                            // byte-offset entries, as k_step expects
+#define GD_FILL(PER, S, CNT) hipLaunchKernelGGL((k_fill<PER, true, S, CNT>), gridx, block, lds, st, p)
+        if (what == 1) {
+            if (p.periodic) { if (s16) GD_FILL(true, true, true); else GD_FILL(true, false, true); }
+            else { if (s16) GD_FILL(false, true, true); else GD_FILL(false, false, true); }
+        } else {
+            if (p.periodic) { if (s16) GD_FILL(true, true, false); else GD_FILL(true, false, false); }
+            else { if (s16) GD_FILL(false, true, false); else GD_FILL(false, false, false); }
+        }
+#undef GD_FILL
     } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false, false>), gridx, block, 0, st, p);
     else hipLaunchKernelGGL((k_fill<false, false, false>), gridx, block, 0, st, p);
 }
@@ -2137,8 +2211,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_pairs(const PairsP p)
         if (dx * dx + dy * dy + dz * dz > p.lim2) count[1] = 1ull;
     } else cnt = 0;
     const size_t gl = TILED ? gt : rbase + slot;
-    const unsigned PER = TILED ? 8u : 4u, NC = p.W / PER;
-    const uint4 *__restrict__ lst = (TILED ? (const uint4 *)p.nbr16 : (const uint4 *)p.nbr) + (size_t)(gl >> 6) * NC * 64 + (gl & 63);
+    const uint2 wrow = TILED ? p.wtab[gl >> 6] : make_uint2(0u, 0u);      // (tiled lists: the ragged rows of the thread's wave)
+    const unsigned PER = TILED ? 8u : 4u, NC = TILED ? wrow.y : p.W / PER;
+    const uint4 *__restrict__ lst = TILED ? (const uint4 *)p.nbr16 + ((size_t)wrow.x * 64 + (gl & 63)) : (const uint4 *)p.nbr + (size_t)(gl >> 6) * NC * 64 + (gl & 63);
     auto partner = [&](unsigned k) -> unsigned {       // slot of list entry k (tiled: near chunks from the front, far chunks from the back)
         const unsigned c = k / PER;
         const uint4 q = lst[(size_t)(TILED && c >= nA ? NC - 1u - (c - nA) : c) * 64];
@@ -2297,10 +2372,14 @@ hipError_t gd_kernels_init_device(void)
 #undef GD_AS_ALL
 #undef GD_AS_PK
 #undef GD_AS
-    set(reinterpret_cast<const void *>(&k_fill<false, true, false>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<false, true, true>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<true, true, false>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<true, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, false, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, true, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, false, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, true, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, false, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, false, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, true, true>), 128 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<0>), 64 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<1>), 64 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<2>), 64 * 1024);

@@ -42,6 +42,7 @@ enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
 // flags[r*GD_NFLAGS + k]
 enum { GD_FLAG_VIOLATION = 0, GD_FLAG_OVERFLOW = 1, GD_FLAG_MAXDISP2 = 2, GD_FLAG_NEED_W = 3, GD_FLAG_TILE_OVERFLOW = 4,
        GD_FLAG_NEED_TILE = 5, GD_FLAG_TAINT = 6, GD_FLAG_NCELL = 7, GD_NFLAGS = 8 };
+// GD_FLAG_OVERFLOW bits: 1 a row is too narrow for its list, 2 a list class beyond its field of the tiled record, 4 the row pool is full
 // GD_FLAG_NCELL: cells of the replica's grid at the last build (sizes the scan's launch at the next one)
 // GD_FLAG_TAINT: set by a list build that starts after an overflow was flagged in the same chunk -- the steps since ran on
 // incomplete lists, the positions are no basis for sizing anything: such a build reports no needs (the chunk is rolled back)
@@ -158,8 +159,10 @@ struct StepParams {
     const unsigned *nbr;
     const unsigned short *nbr16;        // tiled path: tile-local indices
     const TileDesc *tiles;              // [R][nblk]
+    const uint2 *wtab;                  // tiled lists: [R * Np / 64] per k_step WAVE, x = first KiB of the wave's rows in nbr16 (a KiB = one
+                                        // 16-byte chunk of 64 lanes), y = chunks per lane of those rows (ragged rows: every wave has its own width)
     const unsigned *meta;               // bdeg | psmask << 8 | list length << 16
-    unsigned W, WB;                     // list width (entries), bond adjacency width (entries, multiple of 4)
+    unsigned W, WB;                     // generic lists: row width (entries); bond adjacency width (entries, multiple of 4)
     float mob_uniform;                  // >= 0: every bead has this mobility (mob[] is not read)
     int tiled;                          // 1: LDS-tiled path
     int pk;                             // 1: softcore<2,3> + softcore<8,3> specialisation
@@ -273,6 +276,18 @@ struct BuildParams {
     unsigned long long *lcount;         // [R] directed list entries
     float4 *rec_x0; uint2 *rec_mo;      // per-thread records of the tiled path (see StepParams)
     unsigned char *len_prev;            // [R*N] by bead id: list batches at the previous build (the balancing sort key)
+    // Ragged rows of the tiled lists.  The rows of one k_step wave (64 threads, ordered by list length: near-uniform lists) are as
+    // wide as the wave's longest list needs; a build takes them from one pool (nbr16) with a bump cursor, one atomic per block.
+    // The width has to be known before the first entry is written: it is PREDICTED from what each bead needed at the build before
+    // (need_prev, + an eighth and a chunk to spare per class); a bead that outgrows its wave's width flags GD_FLAG_OVERFLOW as a
+    // row overflow always did -- the chunk is rolled back and the next build is EXACT: a counting pass of k_fill first (tests only,
+    // no rows: it records every bead's need), the host sizes the pool from its total, then the filling pass with those needs.
+    uint2 *wtab;                        // [R * Np / 64] (first KiB, chunks per lane) per k_step wave
+    unsigned short *need_prev;          // [R*N] by bead id: near chunks (10 bits) | far chunks << 10 (6 bits) the last build counted
+    unsigned *pool;                     // [0] cursor of the filling pass (KiB taken so far; its final value is the pool's use),
+                                        // [1] KiB a counting pass found the rows to need; both zeroed by k_scan
+    unsigned pool_cap;                  // KiB of the pool
+    int exact;                          // need_prev holds the needs of THIS build (a counting pass ran): no slack
     unsigned long long *dbg;            // section stamps of timing-only builds (the force-output buffer)
 };
 
@@ -280,7 +295,8 @@ struct BuildParams {
 hipError_t gd_kernels_init_device(void);      // LDS opt-in of every kernel that needs it, on the current device (once per device: gd_create)
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
 void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st);     // k_ctx: 0 final callback, 1 fold reaction partials
-void gd_launch_build(const BuildParams &p, hipStream_t st);
+// what: 0 the whole chain with the filling pass; 1 the chain with the counting pass of k_fill (tiled lists); 2 the filling pass alone
+void gd_launch_build(const BuildParams &p, hipStream_t st, int what = 0);
 // Droplet attraction among a small set of target beads (gd_set_pair_softwell): all pairs, one thread per target.
 struct SoftwellP {
     const float4 *pos_in;       // positions the forces are evaluated on (slot order)
@@ -301,7 +317,7 @@ void gd_launch_softwell(const SoftwellP &p, int mode, hipStream_t st);
 struct PairsP {
     const float4 *pos, *x0;             // current positions (slot order); build positions: rec_x0 (tiled, thread order) or xb (slot order)
     const uint2 *rec_mo; const unsigned *meta, *orig;
-    const unsigned *nbr; const unsigned short *nbr16; const TileDesc *tiles;
+    const unsigned *nbr; const unsigned short *nbr16; const TileDesc *tiles; const uint2 *wtab;
     unsigned N, Np, nblk, r, W;
     int tiled, s16, periodic;
     float box[3], inv_box[3];

@@ -12,7 +12,8 @@
 // number of GPU nodes the kernel driver lists.  Exit status: the largest child status.
 // Each driver process is bound to its GPU's share of the CPUs this launcher may run on (share g of G, contiguous): the stepping
 // thread, its packing pool and the writer thread of one GPU do not migrate over, or contend with, those of another
-// (--no-bind turns that off).  When every process has ended the launcher prints one summary line per device:
+// (--no-bind turns that off).  A batched driver prints its own device's rate when it ends ("[rate] device g: ... bead-steps/s");
+// when every process has ended the launcher prints one summary line per device:
 //   [farm] gpu g: <n> file(s), status <s>, <t> s, cpus <first>-<last>
 #include <sched.h>
 #include <spawn.h>

@@ -111,6 +111,8 @@ public:
         TIMED("writer_wait");
         _writer.drain();
     }
+    // bead-steps of the whole run (all files of this process): what a farm's per-device rate is made of
+    double bead_steps() const { return (double)_n * (double)_R * (double)(_config.relaxation_steps + _config.interphase_steps); }
     void report(char const *phase)      // (--timing) the list statistics of the handle at the end of a phase
     {
         g_timing.note(std::string(phase) + ": " + std::to_string(_energy_calls) + " energy evaluations so far, " + std::to_string(_energy_builds) +
@@ -411,12 +413,20 @@ int main(int argc, char **argv)
             TIMED("open_files");
             for (auto const &f : files) stores.push_back(std::make_unique<gd::trajectory_store>(f));
         }
+        double bead_steps = 0;
         {
             simulation_driver driver{stores, device, auto_skin};
             driver.run();
+            bead_steps = driver.bead_steps();
         }
         { TIMED("close_files"); stores.clear(); }
-        g_timing.add("total", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+        double const total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        g_timing.add("total", total_s);
+        // a batched run (the farm's unit: one process per GPU) reports its device's rate, files opened to files closed -- the first
+        // 8-GPU run of gd_farm yields the scaling table from these lines alone (a solo run keeps the reference's output)
+        if (files.size() > 1 || timing)
+            std::clog << "[rate] device " << device << ": " << files.size() << " file(s), " << bead_steps << " bead-steps in " << total_s << " s = "
+                      << bead_steps / total_s << " bead-steps/s\n";
         if (timing) g_timing.print();
     } catch (std::exception const &e) {
         std::cerr << "error: " << e.what() << '\n';

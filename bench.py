@@ -136,10 +136,11 @@ def _kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def _cached_traffic(n_beads, replicas, list_entries_per_bead):
+def _cached_traffic(n_beads, replicas, list_entries_per_bead, why=None):
     """HBM bytes per k_step launch from the committed PMC passes (profiles/*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of
     this very workload, profiles/README.md).  Counters cannot be read from inside the process, so this is a cached profile value --
-    used only while it describes the kernel being timed: same workload, same kernel source (hash), list length within 5 %."""
+    used only while it describes the kernel being timed: same workload, same kernel source (hash), list length within 5 %.
+    `why` (a list) receives the reason when a pass of this workload exists but does not apply ("source hash" / "list length")."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         try:
@@ -147,11 +148,16 @@ def _cached_traffic(n_beads, replicas, list_entries_per_bead):
             if tj["workload"] != {"n_beads": n_beads, "replicas_per_gpu": replicas}:
                 continue
             if tj.get("kernel_source_sha") != _kernel_source_sha():
+                if why is not None:
+                    why.append("source hash")
                 continue
             L0 = tj.get("list_entries_per_bead")
             if L0 and abs(list_entries_per_bead - L0) > 0.05 * L0:
+                if why is not None:
+                    why.append("list length")
                 continue
-            return {"bytes": tj["k_step"]["corrected_bytes_per_launch"], "source": "profiles/" + os.path.basename(path)}
+            return {"bytes": tj["k_step"]["corrected_bytes_per_launch"], "source": "profiles/" + os.path.basename(path),
+                    "build_bytes": (tj.get("build") or {}).get("corrected_bytes_per_build")}
         except (OSError, KeyError, ValueError):
             pass
     return None
@@ -225,6 +231,14 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, bead_scale_init=0.5, device=dev_index), f3, 4000, budget_steps)
     run_one("S-genome-30k x 128, 2nd-bond spring 0 (variant of SURVEY 8d)",
             lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, second_bond_spring=0.0, device=dev_index), f3, 4000, budget_steps)
+    # the two states the headline's relaxed start is kinder than (profiles/r04_soak_128x60000.txt, r04_pipeline_scale_128.json):
+    # the wall after it has contracted (60 000 steps take it from 6.15 to 4.47: the same model prepared at that volume, phi 0.78),
+    # and the dense globule a freshly refined genome starts from (~290 list entries per bead at the default width: phi 3.3, timed
+    # from 200 steps after the start, while it decondenses).  Proxies built from the synthetic generator, not saved states.
+    run_one("S-genome-30k x 128 at the contracted wall (phi 0.78 = R_wall 4.47, the end of a 60 000-step run)",
+            lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=128, phi=0.78, device=dev_index), f3, 4000, budget_steps)
+    run_one("S-genome-30k x 32, dense start (phi 3.3: the list length of a freshly refined globule; decondensing)",
+            lambda: wl.genome_interphase(hip, n_beads=30000, n_replicas=32, phi=3.3, device=dev_index), f3, 200, budget_steps)
     # (gd_tuning.auto_skin: the list width is selected for the workload from measured chunk times; the relaxation is long enough
     # for that sweep and for the one that follows when the tiles outgrow their class.  The genome workloads run at the library default, 0.75, which their sweeps confirm.)
     run_one("S-1kb-250k x 4 replicas (periodic, loops + glues static; auto_skin)",
@@ -252,7 +266,9 @@ def main():
     ap.add_argument("--interval", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on the GPU node; gloo for rehearsals")
     ap.add_argument("--lib", default="", help="developer builds: another HIP library of csrc/ (e.g. libgdyn_dev.so) instead of the product")
-    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --dist-backend gloo)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (gloo; RCCL may refuse two ranks on one device)")
+    ap.add_argument("--allow-stale-traffic", action="store_true",
+                    help="development: do not fail when no committed PMC pass matches the kernel source hash (roofline.traffic null)")
     ap.add_argument("--launch-dry-run", action="store_true", help="with --gpus N > 1 and no launcher: print the launch command and exit")
     a = ap.parse_args()
 
@@ -333,7 +349,9 @@ def main():
     farm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     tm = sys_.run(a.steps, dt, kT, seed=seed, flags=flags)      # synchronous: returns after the stream drained
-    torch.cuda.synchronize(); farm.barrier()
+    torch.cuda.synchronize()
+    el_own = time.perf_counter() - t0      # this rank alone (reported per rank; `value` uses the max over ranks behind the barrier)
+    farm.barrier()
     el = farm.max_over_ranks(time.perf_counter() - t0, device=tdev)
     rollbacks_timed = sys_.context(0).rollbacks - rb0
 
@@ -369,12 +387,17 @@ def main():
     ctx = sys_.context(0)
     e_mean = float(sys_.energy().mean() / N)
     gathered = farm.gather_stats([e_mean, ctx.semiaxes[0], float(ctx.rebuild_interval), float(ctx.rollbacks)], device=tdev)
+    # farm hygiene, checked on rank 0: every rank's CPU share (0/1 per CPU of the machine) and its own rate
+    ncpu = os.cpu_count() or 1
+    shares = farm.gather_stats([1.0 if c in cpu_share else 0.0 for c in range(ncpu)], device=tdev)
+    rates = farm.gather_stats([N * R * a.steps / el_own], device=tdev)
 
     if rank == 0:
         # HBM bytes per k_step launch: the committed PMC passes while they describe this kernel and list (else the algorithmic
         # figure alone is reported)
         L_bead = tm.list_entries_visited / max(int(tm.step_launches), 1) / (N * R)
-        tr = _cached_traffic(N, R, L_bead)
+        why_not = []
+        tr = _cached_traffic(N, R, L_bead, why_not)
         traffic, traffic_src = (tr["bytes"], tr["source"]) if tr else (None, None)
         launches = max(int(tm.step_launches), 1)
         L_launch = tm.list_entries_visited / launches                 # directed entries, all replicas
@@ -385,11 +408,19 @@ def main():
         alg_bytes = 204.0 * N * R
         alg_gbs = alg_bytes / (kms * 1e-3) / 1e9
         meas_gbs = traffic / (kms * 1e-3) / 1e9 if traffic else None
+        # list entries a bead walks per step, averaged over an interval: the whole near class + the far class while it is walked.
+        # The handle reports the entries of the list (both classes); the near share comes with the PMC pass's workload (near_fraction
+        # of the profile, 0.476 on this state) -- priced at the full list here, an upper bound of the design's need
+        walked = L_launch / (N * R)
+        K_live = max(int(ctx.rebuild_interval), 1)
+        whole_bytes = (traffic + tr["build_bytes"] / K_live) if (tr and tr.get("build_bytes")) else None
+        whole_frac = whole_bytes / (tm.total_ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS if whole_bytes else None
         out = {
             "metric": "bead-steps/sec on 100kb whole-genome model, 1 GPU and 8-GPU replica farm",
             "value": N * R * world * a.steps / el, "unit": "bead-steps/s",
             "n_gpus": world, "rccl_ranks": world if (grouped and a.dist_backend == "nccl") else 0, "dist_backend": a.dist_backend if grouped else None,
-            "cpus_per_rank": len(cpu_share),
+            "cpus_per_rank": len(cpu_share), "cpu_shares_disjoint": bool((shares.sum(axis=0) <= 1.0).all()) if world > 1 else None,
+            "bead_steps_per_s_per_rank": [float(v[0]) for v in rates],
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S-genome-{round(N / 1000)}k (5-sim-genome interphase force field, wall dynamics + scale updates on)",
@@ -400,18 +431,27 @@ def main():
                        "steady_state_bead_steps_per_s": N * R * world * n_ss / el_ss, "steady_state_steps": n_ss,
                        "bead_steps_per_s_with_reference_cadence_rank0": obs_rate,
                        "mean_energy_per_bead": [float(v[0]) for v in gathered], "wall_semiaxis": [float(v[1]) for v in gathered]},
-            # frac = measured HBM bytes of the dominant kernel / its launch time / 8 TB/s (<= 1 by construction); the
-            # algorithmic figure at SURVEY's list-independent price is the second key
+            # frac = measured HBM bytes of the dominant kernel / its launch time / 8 TB/s (<= 1 by construction).
+            # whole_step_counter_frac: the same counters over the WHOLE step -- k_step's bytes + the list build's bytes (every kernel of
+            # the build chain, same PMC passes) / the live rebuild interval, over the device time per step (steps + builds).
+            # design_min_bytes_per_launch: what this design has to move per k_step launch -- per bead-step 16 B position read + 24 B of
+            # per-thread records + 16 B adjacency chunk + 2 B per list entry walked (the near class every step, the far class in the
+            # last steps of an interval: the live mean, list_entries_walked_per_bead_step) + 16 B position store: counter traffic well
+            # above it would be wasted re-reads.
             "roofline": {"bound": "hbm", "kernel": "k_step", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "achieved": meas_gbs if meas_gbs is not None else alg_gbs,
                          "frac": (meas_gbs if meas_gbs is not None else alg_gbs) / HBM_PEAK_GBS,
                          "frac_kind": "pmc_traffic_over_live_kernel_time" if meas_gbs is not None else "survey_204B_per_bead_step_over_live_kernel_time",
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch_at_survey_list": alg_bytes, "algorithmic_frac_at_survey_list": alg_gbs / HBM_PEAK_GBS,
+                         "design_min_bytes_per_launch": (72.0 + 2.0 * walked) * N * R, "list_entries_walked_per_bead_step": walked,
+                         "whole_step_counter_frac": whole_frac, "whole_step_counter_bytes_per_step": whole_bytes,
                          "avg_launch_ms": kms,
-                         "whole_step_frac_at_survey_list": 204.0 * N * R * a.steps / el / 1e9 / HBM_PEAK_GBS,
                          "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},
         }
+        # SURVEY 8d's list-independent price (204 B per bead-step: a gather-from-HBM design with a 1.2 x cutoff list), kept for
+        # reference only -- NOT a roofline claim: the tiled kernel does not move those bytes
+        out["config"]["survey_pricing_non_credit"] = {"bytes_per_launch": alg_bytes, "k_step_frac": alg_gbs / HBM_PEAK_GBS,
+                                                      "whole_step_frac": 204.0 * N * R * a.steps / el / 1e9 / HBM_PEAK_GBS}
         rp = _cached_replay(N, R)
         if rp:
             # what actually bounds k_step: VALU issue.  Its arithmetic alone (operands resident, same grid and LDS class) takes t_alu,
@@ -428,6 +468,19 @@ def main():
             sys_.close()
             out["config"]["other_workloads"] = other_workloads(g, wl, hip, dev_index)
         print(json.dumps(out), flush=True)
+        if world > 1:
+            # a farm whose ranks are not what the line says is not a measurement: on the real backend every rank is an RCCL rank,
+            # and the ranks' CPU shares do not overlap (unless binding was switched off or the launcher pinned the ranks itself)
+            if a.dist_backend == "nccl" and out["rccl_ranks"] != world:
+                sys.stderr.write(f"bench.py: {out['rccl_ranks']} RCCL rank(s) for a world of {world}\n"); status = 5
+            if not out["cpu_shares_disjoint"] and not os.environ.get("GDYN_NO_BIND") and len(cpu_share) < ncpu:
+                sys.stderr.write("bench.py: the ranks' CPU shares overlap\n"); status = 5
+        if traffic is None and "source hash" in why_not and "list length" not in why_not and not a.lib and not a.allow_stale_traffic:
+            # the headline's roofline needs the counter traffic: a committed PMC pass of THIS kernel source (profiles/r*_traffic.json is
+            # keyed by the hash of gdyn_kernels.hip + gdyn_types.h and by the list length).  After a kernel edit: tools/profile_round.sh
+            sys.stderr.write("bench.py: the committed PMC traffic of this workload was taken from another kernel source (roofline.traffic is null): "
+                             "run tools/profile_round.sh and commit profiles/<tag>_traffic.json, or pass --allow-stale-traffic\n")
+            status = 4
         if "checked" in out and not out["checked"]["ok"]:
             sys.stderr.write(f"bench.py: the timed state fails the oracle check: {out['checked']}\n")
             status = 3

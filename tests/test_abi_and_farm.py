@@ -135,6 +135,7 @@ def test_bench_farm_rehearsal_two_ranks_one_gpu(hip):
     assert line["value"] > 0 and line["steps"] == 40 and line["warmup"] == 10
     assert len(line["config"]["mean_energy_per_bead"]) == 2          # one summary row gathered from each rank
     assert line["config"]["mean_energy_per_bead"][0] != line["config"]["mean_energy_per_bead"][1]      # independent trajectories
+    assert line["cpu_shares_disjoint"] is True and len(line["bead_steps_per_s_per_rank"]) == 2 and min(line["bead_steps_per_s_per_rank"]) > 0
 
 
 @pytest.mark.gpu
@@ -234,3 +235,25 @@ def test_no_launcher_keeps_an_unsynchronised_once_flag():
     assert code.count("hipFuncAttributeMaxDynamicSharedMemorySize") == 1      # (the one lambda of gd_kernels_init_device)
     capi = open(os.path.join(ROOT, PKG_DIR, "csrc", "gdyn_capi.hip")).read()
     assert "gd_kernels_init_device()" in capi and "DeviceOnce" in capi
+
+
+@pytest.mark.gpu
+def test_bench_two_rccl_ranks_on_one_device_or_the_refusal_recorded(hip):
+    """8-GPU readiness as far as one GPU goes: `bench.py --gpus 2` on the REAL backend (nccl = RCCL) with both ranks on GPU 0.  RCCL
+    may refuse two ranks on one device (it did on the pool's image: the refusal text becomes the skip reason, so the record shows
+    what was attempted); where it is allowed, the line must carry rccl_ranks == 2, disjoint CPU shares and one rate per rank."""
+    import json
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--dist-backend", "nccl", "--single-device", "--beads", "3000", "--replicas", "8",
+                          "--equil", "200", "--steps", "40", "--warmup", "10", "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1", NCCL_DEBUG="WARN"))
+    if out.returncode != 0:
+        text = out.stderr + out.stdout
+        refusal = [ln.strip() for ln in text.splitlines() if "Duplicate GPU" in ln or "invalid usage" in ln.lower() or "ncclInvalidUsage" in ln]
+        assert refusal, text[-3000:]      # any other failure is a failure
+        pytest.skip("RCCL refuses two ranks on one device: " + refusal[0][:300])
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dist_backend"] == "nccl"
+    assert line["cpu_shares_disjoint"] is True and len(line["bead_steps_per_s_per_rank"]) == 2
+    assert line["config"]["global_replicas"] == 16 and line["value"] > 0

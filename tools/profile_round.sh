@@ -7,11 +7,11 @@ root=$GRAFT_REPO_ROOT; out=$root/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 python3 $root/bench.py --save-state /tmp/state.npy > /dev/null 2>&1
 echo "[profile] state saved"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $root/bench.py --load-state /tmp/state.npy --warmup 300 --steps 1000 --no-cpu-baseline --no-extra > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $root/bench.py --load-state /tmp/state.npy --warmup 300 --steps 1000 --no-cpu-baseline --no-extra --allow-stale-traffic > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_bench_under_rocprof.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
 python3 $root/tools/kstats.py /tmp/prof_stats > $out/${tag}_bench_kernel_stats.txt
 echo "[profile] kernel stats done"
-PMC_SCRIPT=bench.py bash $root/tools/pmc.sh $tag --load-state /tmp/state.npy --warmup 200 --steps 200 --no-cpu-baseline --no-extra
+PMC_SCRIPT=bench.py bash $root/tools/pmc.sh $tag --load-state /tmp/state.npy --warmup 200 --steps 200 --no-cpu-baseline --no-extra --allow-stale-traffic
 cp $out/pmc_$tag/summary.txt $out/${tag}_bench_pmc_summary.txt
 echo "[profile] pmc done"
 # ---- S-1kb-250k x 16 (periodic, tiled rows): relaxed with the skin selection first (not profiled), then kernel stats + the
@@ -34,7 +34,7 @@ if [ -f 2022a-genome-dynamics_amd/csrc/libgdyn_abl41.so ]; then
   [ -x tools/ubench/valu_rate ] && ./tools/ubench/valu_rate > $out/${tag}_valu_rate.txt 2>&1
   echo "[profile] replay done"
 fi
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --allow-stale-traffic > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "[profile] driver-line bench done"
-python3 bench.py --no-cpu-baseline --no-extra > $out/${tag}_bench_2000steps.json 2> $out/${tag}_bench_2000steps.err
+python3 bench.py --no-cpu-baseline --no-extra --allow-stale-traffic > $out/${tag}_bench_2000steps.json 2> $out/${tag}_bench_2000steps.err
 tail -c 300 $out/${tag}_bench_2000steps.json
