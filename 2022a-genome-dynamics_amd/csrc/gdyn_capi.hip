@@ -161,10 +161,9 @@ struct gd_system {
     // nbr16 IS the pool: pool KiB = nbr16.n / 512 entries.
     DevBuf<uint2> wtab; DevBuf<unsigned short> need_prev; DevBuf<unsigned> pool;
     bool need_valid = false;       // need_prev describes the state about to be listed well enough to predict row widths from it
-    bool need_exact = false;       // ... and comes from a counting pass of these very positions (build_now's retry after an overflow)
     float need_rv = 0; bool need_all_near = false;      // list radius / class mode need_prev was counted at
-    uint32_t pool_used = 0;        // KiB the last filling pass took (its cursor's final value; beyond the pool's size when that was full)
-    uint32_t pool_used_exact = 0;  // 1: that pass was exact (no slack in it: the next, predicted, one takes an eighth + 2 KiB per wave more)
+    uint32_t pool_used = 0;        // KiB the last build took (its cursor's final value: the need, when the pool was full)
+    uint32_t repairs = 0;          // k_step waves the last build read back had to repair (diagnostics)
     DevBuf<float> bbox;
     DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<int4> chain;
     float mob_uniform = -1.f;
@@ -866,38 +865,23 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
     b.wtab = s->wtab.p; b.need_prev = s->need_prev.p; b.pool = s->pool.p;
     if (tiled) {
-        // Ragged rows (BuildParams): every k_step wave's rows are as wide as its longest list.  A WARM build predicts the widths from
-        // what each bead needed at the build before and takes the rows from the pool as it goes; a COLD one -- no history (first
-        // build, positions from the caller, a rolled-back overflow), another list radius or class mode -- counts first: the chain
-        // with the counting pass of k_fill, the pool sized from its total, then the filling pass with exact widths.
+        // Ragged rows (BuildParams): every k_step wave's rows are as wide as its longest list, predicted from what each bead needed at
+        // the build before (no history -- first build, positions from the caller, another list radius or class mode: W entries per
+        // bead) and repaired inside k_fill where a list outgrows the prediction.  The pool (nbr16) is sized from the use of the last
+        // build with an eighth + a KiB per wave to spare (the use is read back with every chunk; the builds in between grow with the
+        // lists); a pool that turns out too small is flagged, its cursor has counted the need, and the chunk is rolled back.
         const size_t waves = (size_t)s->R * s->Np / 64;
-        const bool cold = !s->need_valid || s->need_all_near != s->all_near || !(s->need_rv > 0) || std::fabs(rv / s->need_rv - 1.f) > 0.02f;
+        const bool predict = s->need_valid && s->need_all_near == s->all_near && s->need_rv > 0 && std::fabs(rv / s->need_rv - 1.f) <= 0.02f;
         auto pool_kib = [&]() { return (size_t)(s->nbr16.n / 512); };
-        auto size_pool = [&](size_t want_kib) -> hipError_t {      // (not preserved: the list in it is about to be rebuilt)
-            if (pool_kib() >= want_kib && pool_kib() <= 2 * want_kib + 4 * waves) return hipSuccess;
-            return s->nbr16.resize((want_kib + want_kib / 16 + waves) * 512, false);
-        };
-        if (cold) {
-            b.exact = 1; b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
-            gd_launch_build(b, s->stream, 1);
-            unsigned pw[2] = {0u, 0u};
-            HIPCHK(hipMemcpyAsync(pw, s->pool.p, sizeof pw, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipStreamSynchronize(s->stream));
-            HIPCHK(size_pool(std::max<size_t>(pw[1], waves)));
-            b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
-            gd_launch_build(b, s->stream, 2);
-            s->pool_used = pw[1]; s->pool_used_exact = 1;
-        } else {
-            // (the pool's use is read back with every chunk; the builds in between grow with the lists: an eighth to spare on top of
-            // the slack the predicted widths carry themselves -- an eighth + a chunk per class and wave over an exact pass's total)
-            const size_t used = std::max<size_t>(s->pool_used, waves);
-            HIPCHK(size_pool(s->pool_used_exact ? used + used / 4 + 3 * waves : used + used / 8 + waves));
-            b.exact = 0; b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
-            gd_launch_build(b, s->stream, 0);
-            s->pool_used_exact = 0;
-        }
+        const size_t used = predict ? std::max<size_t>(s->pool_used, waves) : std::max<size_t>(s->pool_used, waves * (s->W / 8));
+        const size_t want = used + used / 8 + 2 * waves;
+        if (pool_kib() < want || pool_kib() > 2 * want + 4 * waves) HIPCHK(s->nbr16.resize((want + want / 16) * 512, false));      // (not preserved: the list in it is about to be rebuilt)
+        if (dev_env("GDYN_DEBUG") && dev_env("GDYN_DEBUG")[0] == '2')
+            fprintf(stderr, "[gdyn] build %llu: %s, rows used %u KiB, pool %zu KiB, rv %.4f\n", (unsigned long long)s->rebuilds, predict ? "predicted" : "no history", s->pool_used, pool_kib(), rv);
+        b.predict = predict ? 1 : 0; b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
         s->need_valid = true; s->need_rv = rv; s->need_all_near = s->all_near;
-    } else gd_launch_build(b, s->stream, 0);
+    }
+    gd_launch_build(b, s->stream);
     s->bbox_cur ^= 1; s->bbox_valid = tiled;      // (the box of the positions this build sorted, reduced by k_tiles: the next build's grid)
     s->list_tiled = tiled; s->list_tile_cap = s->tile_cap;
     s->w_packed = s->packed_ab;
@@ -912,13 +896,18 @@ static int read_flags(gd_system *s, std::vector<unsigned> &f)
     HIPCHK(hipGetLastError());
     f.resize((size_t)s->R * GD_NFLAGS);
     HIPCHK(hipMemcpyAsync(f.data(), s->flags.p, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
-    unsigned used = 0;
-    HIPCHK(hipMemcpyAsync(&used, s->pool.p, sizeof used, hipMemcpyDeviceToHost, s->stream));
+    unsigned used[4] = {0u, 0u, 0u, 0u};
+    HIPCHK(hipMemcpyAsync(used, s->pool.p, sizeof used, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (s->list_tiled && used > 0) s->pool_used = used;
+    if (s->list_tiled && used[0] > 0) { s->pool_used = std::max(used[0], used[1]); s->repairs = used[2]; }
     return GD_OK;
 }
-static int clear_flags(gd_system *s) { HIPCHK(hipMemsetAsync(s->flags.p, 0, (size_t)s->R * GD_NFLAGS * sizeof(unsigned), s->stream)); return GD_OK; }
+static int clear_flags(gd_system *s)
+{
+    HIPCHK(hipMemsetAsync(s->flags.p, 0, (size_t)s->R * GD_NFLAGS * sizeof(unsigned), s->stream));
+    HIPCHK(hipMemsetAsync(s->pool.p + 1, 0, 2 * sizeof(unsigned), s->stream));      // the row pool's largest use and repair count of the builds to come
+    return GD_OK;
+}
 
 // Tile capacities (float4 entries) at which k_step still fits 3, 2, 1 blocks into the 160 KB of LDS of a CU
 // (1.2 KB static LDS per block on top of the tile).
@@ -1014,10 +1003,10 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         else { s->tiled_ok = false; s->tiled_off = 1; }     // too dense for one tile: generic path (retried later with back-off)
     }
     if (over) {
-        // Tiled lists (ragged rows): a bead outgrew the rows predicted for its wave, or the pool was full -- the next build is a cold
-        // one, it counts before it fills.  Generic lists (uniform rows): the overflowing build has counted the longest list exactly (a
-        // row keeps counting past its width): the next build gets that width with 6 % to spare.
-        s->need_valid = false;
+        // Tiled lists (ragged rows): the pool was full -- its cursor counted on, pool_used is the need and the next build sizes the pool
+        // from it (a list that outgrows its predicted row is repaired inside k_fill and never gets here).  Generic lists (uniform
+        // rows): the overflowing build has counted the longest list exactly (a row keeps counting past its width): the next build
+        // gets that width with 6 % to spare.
         if (!s->list_tiled) {
             unsigned w = need_w + need_w / 16 + 8;
             s->W = std::max(w, s->W + 8);
@@ -1046,8 +1035,12 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
                     gp[r].ncell, gp[r].org[0], gp[r].org[1], gp[r].org[2], gp[r].inv[0], f[r * GD_NFLAGS + GD_FLAG_NEED_TILE]);
     }
     if ((over || tover) && dev_env("GDYN_DEBUG"))
-        fprintf(stderr, "[gdyn] overflow: list %d (need %u -> W %u), tile %d (need %u -> cap %u, tiled_ok %d)\n", (int)over, need_w, s->W,
-                (int)tover, need_t, s->tile_cap, (int)s->tiled_ok);
+    {
+        unsigned bits = 0;
+        for (uint32_t r = 0; r < s->R; r++) bits |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW];
+        fprintf(stderr, "[gdyn] overflow: list %d (bits %u, need %u -> W %u; rows %u KiB of a pool of %zu), tile %d (need %u -> cap %u, tiled_ok %d)\n", (int)over, bits,
+                need_w, s->W, s->pool_used, (size_t)(s->nbr16.n / 512), (int)tover, need_t, s->tile_cap, (int)s->tiled_ok);
+    }
     return over || tover;
 }
 
@@ -1340,6 +1333,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
     }
 
     int64_t done = 0;
+    int chunk_retries = 0;     // consecutive rollbacks of the chunk in progress
     float last_dmax2 = 0;      // largest bound, over the replicas, of the squared displacement since the build of the positions the last accepted chunk WROTE
     while (done < run->steps) {
         // ---- one verified chunk
@@ -1433,7 +1427,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         {
             const size_t nf = f.size() * sizeof(unsigned), nc = s->R * sizeof(DevCtx), nl = s->R * sizeof(unsigned long long), nd = s->R * sizeof(float);
             if (!s->h_chunk) HIPCHK(hipHostMalloc((void **)&s->h_chunk, nf + nc + nl + nd + 16, hipHostMallocDefault));
-            HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc + nl + nd, s->pool.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));      // the row pool's use
+            HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc + nl + nd, s->pool.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));      // the row pool's use
             HIPCHK(hipMemcpyAsync(s->h_chunk, s->flags.p, nf, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(s->h_chunk + nf, s->ctx[s->ccur].p, nc, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc, s->lcount_d.p, nl, hipMemcpyDeviceToHost, s->stream));
@@ -1445,7 +1439,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
             memcpy(f.data(), s->h_chunk, nf); memcpy(ctx_new.data(), s->h_chunk + nf, nc); memcpy(s->lcount.data(), s->h_chunk + nf + nc, nl);
             last_dmax2 = 0;
             for (uint32_t r = 0; r < s->R; r++) { float d2; memcpy(&d2, s->h_chunk + nf + nc + nl + r * sizeof(float), 4); last_dmax2 = std::max(last_dmax2, d2); }
-            { unsigned used = 0; memcpy(&used, s->h_chunk + nf + nc + nl + nd, 4); if (s->list_tiled && used > 0) s->pool_used = used; }
+            { unsigned used[4]; memcpy(used, s->h_chunk + nf + nc + nl + nd, 16); if (s->list_tiled && used[0] > 0) { s->pool_used = std::max(used[0], used[1]); s->repairs = used[2]; } }
         }
         bool violated = false; float maxd2 = 0;
         for (uint32_t r = 0; r < s->R; r++) {
@@ -1456,6 +1450,10 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         if (violated || over) {
             // roll the chunk back: restore bead-order positions + context, shorten the interval / widen the list
             s->rollbacks++;
+            // (every cause of a rollback changes what the retry runs with -- interval, skin, pool, tile class, list path -- so a chunk
+            // converges in a few attempts; a chunk that does not is a defect, reported instead of retried for ever)
+            if (++chunk_retries > 24) return fail(GD_ESTATE, "gd_run: a chunk of %lld steps at step %lld was rolled back %d times (%s): giving up",
+                                                  (long long)chunk, (long long)s->hctx[0].step, chunk_retries, over ? "list / tile / pool overflow" : "skin violation");
             if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] rollback %llu: %s, K %u, skin %.3f, chunk of %lld steps at step %lld\n", (unsigned long long)s->rollbacks,
                                                over ? "overflow" : "skin violation", s->K, s->skin, (long long)chunk, (long long)s->hctx[0].step);
             HIPCHK(hipMemcpy2DAsync(s->pos[s->pcur].p, (size_t)s->Np * sizeof(float4), s->snap.p, (size_t)s->N * sizeof(float4),
@@ -1517,7 +1515,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         }
         if (with_list) tune_skin(s, ms, chunk, full_interval, false);
         if (with_list && full_interval) class_skin(s, run);
-        done += chunk;
+        done += chunk; chunk_retries = 0;
     }
     // The last chunk was accepted: every bead is within the margin the list in use was built for, at the cutoff of the last step.
     // That is still the cutoff an observation sees when the scales did not move behind that step (callback deferred, or no scale

@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
     unsigned t0 = blockIdx.y * GD_SCAN_TILE;
     if (blockIdx.y == 0 && tid == 1023) {      // the per-build words of the replica start over (the last wave: off the path of the scan)
         p.lcount[r] = 0ull;
-        if (r == 0 && p.pool) { p.pool[0] = 0u; p.pool[1] = 0u; }      // the row pool's cursor and the counting pass's total (BuildParams)
+        if (r == 0 && p.pool) { p.pool[1] = max(p.pool[1], p.pool[0]); p.pool[0] = 0u; }      // the row pool's cursor starts over; [1] keeps the largest use since the host looked (BuildParams)
         p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
         if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
     }
@@ -1581,12 +1581,9 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
 
 // Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
 // TILED: candidates are read from the block's LDS tile and list entries are tile indices.
-// COUNT (tiled lists): the counting pass of an exact build -- the sort, the tile and the distance tests of the filling pass, no rows,
-// no re-map: every bead's need goes to need_prev, the KiB the rows of the block's waves need to pool[1] (BuildParams).
-template <bool PERIODIC, bool TILED, bool S16, bool COUNT = false>
+template <bool PERIODIC, bool TILED, bool S16>
 __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 {
-    static_assert(TILED || !COUNT, "the counting pass belongs to the ragged rows of the tiled lists");
     GD_FSTAMP_BEGIN();
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     // block totals (list entries, longest list): accumulated by LDS atomics as the waves finish; the last one to finish hands them on --
@@ -1595,15 +1592,15 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     __shared__ unsigned long long s_acc_cnt;
     __shared__ unsigned s_acc_max, s_acc_done;
     // ragged rows: chunks per lane and first KiB of the rows of each of the block's eight k_step waves
-    __shared__ unsigned s_wn[GD_BLOCK / 64], s_woff[GD_BLOCK / 64];
+    __shared__ unsigned s_wn[GD_BLOCK / 64], s_woff[GD_BLOCK / 64], s_wneed[GD_BLOCK / 64];      // (s_wneed: what the lists turned out to need)
     unsigned r, blk;
     if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_acc_cnt = 0ull; s_acc_max = 0u; s_acc_done = 0u; }
-    if (threadIdx.x < GD_BLOCK / 64) { s_wn[threadIdx.x] = 0u; s_woff[threadIdx.x] = 0u; }
+    if (threadIdx.x < GD_BLOCK / 64) { s_wn[threadIdx.x] = 0u; s_woff[threadIdx.x] = 0u; s_wneed[threadIdx.x] = 0u; }
     if (!TILED) __syncthreads();      // (the tiled path has its barriers below)
     const size_t rbase = (size_t)r * p.Np;
-    const unsigned slot = blk * GD_BLOCK + threadIdx.x;
+    unsigned slot = blk * GD_BLOCK + threadIdx.x;      // (slot, gt, o, wk: the thread's own bead -- in the repair pass of a block's last wave, below, another one)
     size_t gt = rbase + slot;
     const size_t g = rbase + slot;
     const float4 *__restrict__ rpos = p.pos_out + rbase;
@@ -1688,16 +1685,19 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         gt = rbase + blk * GD_BLOCK + (unsigned)__shfl((int)(incl - own + before), (int)bin, 64) + rank_w;
     }
     // Ragged rows: the k_step wave a bead goes to (wk) gets rows as wide as the longest PREDICTED list among its 64 beads -- what the
-    // bead needed at the build before, plus an eighth and a chunk per class (exact builds: what the counting pass has just
-    // counted, nothing to spare); at least one chunk, so that k_step's unconditional first chunk load stays inside the pool.
-    const unsigned wk = TILED ? ((unsigned)(gt - rbase) - blk * GD_BLOCK) >> 6 : 0u;
-    if (TILED && !COUNT) {
+    // bead needed at the build before plus an eighth and a chunk per class (no history: the caller's guess, p.W entries); at least one
+    // chunk, so that k_step's unconditional first chunk load stays inside the pool.  A list that outgrows its row is REPAIRED at the
+    // end of the kernel (no rollback): see the repair pass below.
+    unsigned wk = TILED ? ((unsigned)(gt - rbase) - blk * GD_BLOCK) >> 6 : 0u;
+    if (TILED) {
         unsigned want = 1u;
         if (slot < p.N) {
-            const unsigned q = p.need_prev[(size_t)r * p.N + o_pre];
-            unsigned pn = q & 1023u, pf = q >> 10;
-            if (!p.exact) { pn += max(1u, pn >> 3); pf += max(1u, pf >> 3); }
-            want = max(min(pn, GD_TILED_MAX_NEAR / 8u) + min(pf, GD_TILED_MAX_FAR / 8u), 1u);
+            if (p.predict) {
+                const unsigned q = p.need_prev[(size_t)r * p.N + o_pre];
+                unsigned pn = q & 1023u, pf = q >> 10;
+                pn += max(1u, pn >> 3); pf += max(1u, pf >> 3);
+                want = max(min(pn, GD_TILED_MAX_NEAR / 8u) + min(pf, GD_TILED_MAX_FAR / 8u), 1u);
+            } else want = max(p.W / 8u, 1u);
         }
         atomicMax(&s_wn[wk], want);
         __syncthreads();
@@ -1730,12 +1730,12 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         }
         return false;
     };
-    const size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
+    size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
     if (slot < p.N) {
         o = p.orig_out[g];
         deg = p.bdeg_o[o];
     }
-    if (!COUNT && slot < p.N) {
+    if (slot < p.N) {
         const unsigned *so = p.slot_of + (size_t)r * p.N;
         uint4 *__restrict__ adjw = (uint4 *)p.badj + (size_t)(gw >> 6) * (p.WB / 4) * 64 + (gw & 63);
         // one 16-byte adjacency chunk per round: its four gathers (entry by bead, then slot by partner) are in flight
@@ -1768,8 +1768,16 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         }
     }
     GD_FSTAMP(1);     // bond / chain re-map
-    if (TILED && !COUNT) __syncthreads();      // the rows of the block's waves have their place (s_woff, s_wn)
-    if (slot < p.N) {
+    if (TILED) __syncthreads();      // the rows of the block's waves have their place (s_woff, s_wn)
+    // The sweep.  Pass 0: every thread lists its own bead.  Tiled lists, rarely: pass 1, 2, ... -- the block's LAST wave to finish repairs
+    // the rows of a k_step wave in which some list outgrew the predicted width (rows keep counting past their width, so the exact need
+    // is known): fresh rows of that width from the pool, the 64 beads of the wave listed again by the 64 lanes.  No barrier, no
+    // rollback; the abandoned rows stay in the pool until the next build.
+    bool on = slot < p.N;
+    unsigned row_nc = TILED ? s_wn[wk] : 0u, row_off = TILED ? s_woff[wk] : 0u, repaired = 0u;
+    for (unsigned pass = 0;; pass++) {
+    if (pass != 0) cnt = 0;
+    if (on) {
         unsigned listlen = 0, nAq = 0, nB = 0;
         if (!(p.nbr || p.nbr16)) {      // (a sort without lists: the counter of the bead's cell still goes back to zero, see below)
             const GridP gp = p.grid[r];
@@ -1796,8 +1804,8 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // reads (8 x u16 tiled, 4 x u32 generic); a bead's 8 (4) consecutive entries share one chunk.
             constexpr unsigned PER = TILED ? 8u : 4u;
             // (tiled: the rows of the thread's k_step wave -- NC chunks per lane from KiB s_woff[wk] of the pool; generic: uniform rows)
-            const unsigned NC = TILED ? s_wn[wk] : p.W / PER;
-            uint4 *__restrict__ lst = TILED ? (uint4 *)p.nbr16 + ((size_t)s_woff[wk] * 64 + (gw & 63)) : (uint4 *)p.nbr + (size_t)(gw >> 6) * NC * 64 + (gw & 63);
+            const unsigned NC = TILED ? row_nc : p.W / PER;
+            uint4 *__restrict__ lst = TILED ? (uint4 *)p.nbr16 + ((size_t)row_off * 64 + (gw & 63)) : (uint4 *)p.nbr + (size_t)(gw >> 6) * NC * 64 + (gw & 63);
             // the 16-byte chunk under construction lives in four registers (an LDS staging slot per thread would cost
             // the 8 KB that separate two from three resident blocks per CU); every PER-th entry the finished chunk
             // goes out as one 16-byte global store (2-byte scattered global stores were 25% of the build)
@@ -1882,7 +1890,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             mn &= m; m ^= mn;                                 // near class, far class
                             // (lowest set bit first: find-first-bit, then clear it with m & (m - 1) -- three instructions less per entry than
                             // isolating the highest bit; the order of a bead's entries is immaterial)
-                            if (COUNT) { cnt += (unsigned)__popc(mn); cntB += (unsigned)__popc(m); mn = 0u; m = 0u; }
                             while (mn) {
                                 const unsigned bit = (unsigned)__builtin_ctz(mn);
                                 mn &= mn - 1u;
@@ -1945,7 +1952,6 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                             GD_FSTAMP(3);     // distance tests
                             // (lowest set bit first: find-first-bit, then clear it with m & (m - 1) -- three instructions less per entry than
                             // isolating the highest bit; the order of a bead's entries is immaterial)
-                            if (COUNT) { cnt += (unsigned)__popc(mn); cntB += (unsigned)__popc(m); mn = 0u; m = 0u; }
                             while (mn) {
                                 GD_FCOUNT(9);
                                 const unsigned bit = (unsigned)__builtin_ctz(mn);
@@ -1999,100 +2005,121 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // class beyond that does not fit it even when the row is wide enough for the sum -- flagged like a row overflow, bit 1 on
             // top (the host then builds single-class lists, or generic ones beyond 8 184 entries, until the dense transient has passed)
             const bool class_over = TILED && (needA > GD_TILED_MAX_NEAR || needB > GD_TILED_MAX_FAR);
-            // (a counting pass has no rows to overflow: only a class beyond its field counts)
+            // (tiled lists: a row that is too narrow is repaired below, only a class beyond its field is flagged; generic lists: the
+            // host widens the uniform rows and builds again)
             const unsigned Wrow = NC * PER;
-            if (((!COUNT && needw > Wrow) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
+            if (((!TILED && needw > Wrow) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
                 atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], class_over ? 3u : 1u);
                 atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], needw);
             }
             if (TILED) {
-                // what this bead needed, for the rows of the next build (or of the filling pass behind this counting pass); the
-                // k_step wave it goes to needs the sum for its longest list
+                // what this bead needed: for the rows of the next build, and for the repair pass -- the k_step wave it goes to needs
+                // the sum for its longest list
                 const unsigned na8 = min(needA / 8u, GD_TILED_MAX_NEAR / 8u), nb8 = min(needB / 8u, GD_TILED_MAX_FAR / 8u);
                 p.need_prev[(size_t)r * p.N + o] = (unsigned short)(na8 | (nb8 << 10));
-                if (COUNT) atomicMax(&s_wn[wk], max(na8 + nb8, 1u));
+                if (pass == 0) atomicMax(&s_wneed[wk], na8 + nb8);
             }
             listlen = min(found, Wrow);
             nAq = min((cnt + 3u) / 4u, GD_TILED_MAX_NEAR / 4u);            // near entries in fours (the record's count; chunks are still written whole)
-            if (!COUNT) {
-                while (cnt % GD_UNROLL) push(self);
-                flush();
-                if (TILED) while (cntB % GD_UNROLL) push_far(self);
-            }
-            // (an overflowed list is flagged and its chunk rolled back; the chunk counts still have to stay inside the row)
+            while (cnt % GD_UNROLL) push(self);
+            flush();
+            if (TILED) while (cntB % GD_UNROLL) push_far(self);
+            // (an overflowed list: the chunk counts have to stay inside the row until it is repaired)
             nAq = min(nAq, 2u * NC); nB = min(min(cntB / GD_UNROLL, GD_TILED_MAX_FAR / GD_UNROLL), NC - (nAq + 1u) / 2u);
             cnt = found;
         }
         const unsigned meta = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
-        if (COUNT) { }      // (records, sort keys and lists are the filling pass's)
-        else if (TILED) {
+        if (TILED) {
             const float4 xb = rpos[slot];
             p.rec_x0[gt] = make_float4(xb.x, xb.y, xb.z, __uint_as_float(slot - blk * GD_BLOCK));
             // tiled record: bond degree | point-source mask << 8 | block-local slot << 12 | near entries / 4 << 21, bead id | far chunks << 26
-            // (the host keeps the width of tiled lists <= GD_TILED_MAX_W; y all ones: no bead)
+            // (y all ones: no bead)
             p.rec_mo[gt] = make_uint2(deg | (((unsigned)p.psmask_o[o] & 0xfu) << 8) | ((slot - blk * GD_BLOCK) << 12) | (nAq << 21), o | (nB << 26));
             p.len_prev[(size_t)r * p.N + o] = (unsigned char)min(nAq, 255u);       // (the near class is what most steps run over)
         } else p.meta[g] = meta;
     }
-    if (TILED && !COUNT && slot >= p.N) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
-    GD_FSTAMP(5);     // padding, meta
-    unsigned long long c64 = cnt;
-    unsigned cmax = cnt;
-    for (int o = 32; o > 0; o >>= 1) { c64 += __shfl_xor(c64, o, 64); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o, 64)); }
-    if (lane == 0) {
-        atomicAdd(&s_acc_cnt, c64); atomicMax(&s_acc_max, cmax);
-        __threadfence_block();
-        if (atomicAdd(&s_acc_done, 1u) == GD_BLOCK / 64 - 1u) {      // the last wave of the block to finish
-            __threadfence_block();
-            const unsigned long long t = atomicAdd(&s_acc_cnt, 0ull);
-            const unsigned m = atomicMax(&s_acc_max, 0u);
-            if (COUNT) {      // KiB the rows of this block's eight waves need (a wave without a bead: one chunk, as in the filling pass)
-                unsigned kib = 0;
-                for (unsigned w = 0; w < GD_BLOCK / 64; w++) kib += max(atomicMax(&s_wn[w], 0u), 1u);
-                atomicAdd(&p.pool[1], kib);
+    if (pass == 0) {
+        if (TILED && !on) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
+        GD_FSTAMP(5);     // padding, meta
+        unsigned long long c64 = cnt;
+        unsigned cmax = cnt;
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { c64 += __shfl_xor(c64, o2, 64); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o2, 64)); }
+        unsigned last = 0u;
+        if (lane == 0) {
+            atomicAdd(&s_acc_cnt, c64); atomicMax(&s_acc_max, cmax);
+            __threadfence_block();       // (this wave's records and needs are written before it counts as done)
+            if (atomicAdd(&s_acc_done, 1u) == GD_BLOCK / 64 - 1u) {      // the last wave of the block to finish
+                __threadfence_block();
+                const unsigned long long t = atomicAdd(&s_acc_cnt, 0ull);
+                const unsigned m = atomicMax(&s_acc_max, 0u);
+                if (t) atomicAdd(&p.lcount[r], t);
+                if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always
+                last = 1u;
             }
-            if (t && !COUNT) atomicAdd(&p.lcount[r], t);
-            if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always (the host also shrinks W)
+        }
+        GD_FSTAMP(6);     // count
+        if (!TILED || !__builtin_amdgcn_readfirstlane((int)last)) break;
+        __threadfence_block();
+    }
+    // the last wave: the next k_step wave of the block whose lists outgrew their rows (a block without rows -- the pool was full -- is
+    // not repaired: flagged above, the host enlarges the pool)
+    unsigned w = GD_BLOCK / 64;
+    for (unsigned q = 0; q < GD_BLOCK / 64; q++)
+        if (w == GD_BLOCK / 64 && !((repaired >> q) & 1u) && s_wn[q] != 0u && atomicMax(&s_wneed[q], 0u) > s_wn[q]) w = q;
+    if (w == GD_BLOCK / 64) break;
+    repaired |= 1u << w;
+    const unsigned need = max(atomicMax(&s_wneed[w], 0u), 1u);
+    unsigned off = 0u;
+    if (lane == 0) {
+        off = atomicAdd(&p.pool[0], need);
+        if (!(off <= p.pool_cap && need <= p.pool_cap - off)) {
+            if (!p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);
+            off = 0xffffffffu;
+        } else {
+            p.wtab[(rbase + (size_t)blk * GD_BLOCK) / 64 + w] = make_uint2(off, need);
+            atomicAdd(&p.pool[2], 1u);      // (repaired waves of this build: diagnostics)
         }
     }
-    GD_FSTAMP(6);     // count
+    off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+    if (off == 0xffffffffu) break;      // (the pool is full: the rows stay as they are, flagged)
+    row_off = off; row_nc = need; wk = w;
+    gt = rbase + (size_t)blk * GD_BLOCK + w * 64u + lane; gw = gt;
+    {
+        const uint2 mo = p.rec_mo[gt];
+        on = mo.y != GD_REC_NOBEAD;
+        slot = blk * GD_BLOCK + ((mo.x >> 12) & 0x1ffu); o = mo.y & GD_REC_ID_MASK; deg = mo.x & 0xffu;
+    }
+    }
     GD_FSTAMP_END(p.dbg);
 }
 
 #undef s_td
 
-void gd_launch_build(const BuildParams &p, hipStream_t st, int what)
+void gd_launch_build(const BuildParams &p, hipStream_t st)
 {
     const dim3 grid(p.R * p.nblk), block(GD_BLOCK), gridx(p.cpb ? GD_XCDS * p.cpb * p.R : p.R * p.nblk);
-    // five launches: count + rank (the grid laid by every block itself) | scan | scatter (+ the box of the next build's grid) | tile
-    // descriptors | fill (+ the cell counters back to zero).  An open box without a bounding box from the build before (the first build of a handle, positions set by
-    // the caller): k_bbox and k_gridp in front.  what = 2: the filling pass alone, behind a chain that ended in the counting pass (what = 1).
-    if (what != 2) {
-        if (p.periodic) hipLaunchKernelGGL((k_bin<true, true>), grid, block, 0, st, p);
-        else if (p.warm) hipLaunchKernelGGL((k_bin<false, true>), grid, block, 0, st, p);
-        else {
-            hipLaunchKernelGGL(k_bbox, dim3(p.R * ((p.nblk + 3u) / 4u)), block, 0, st, p);
-            hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(GD_GRIDP_THREADS), 0, st, p);
-            hipLaunchKernelGGL((k_bin<false, false>), grid, block, 0, st, p);
-        }
-        hipLaunchKernelGGL(k_scan, dim3(p.R, std::max(1u, p.scan_segments)), dim3(1024), 0, st, p);
-        if (p.periodic) { hipLaunchKernelGGL(k_members<true>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p); }
-        else { hipLaunchKernelGGL(k_members<false>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p); }
-        if (p.tiled && p.periodic) hipLaunchKernelGGL(k_tiles<true>, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
-        else if (p.tiled) hipLaunchKernelGGL(k_tiles<false>, dim3((p.R * p.nblk + 63) / 64 + p.R), dim3(64), 0, st, p);
+    // six launches: count + rank (the grid laid by every block itself) | scan | cell members | scatter (+ the box of the next build's
+    // grid) | tile descriptors | fill (+ the cell counters back to zero).  An open box without a bounding box from the build before
+    // (the first build of a handle, positions set by the caller): k_bbox and k_gridp in front.
+    if (p.periodic) hipLaunchKernelGGL((k_bin<true, true>), grid, block, 0, st, p);
+    else if (p.warm) hipLaunchKernelGGL((k_bin<false, true>), grid, block, 0, st, p);
+    else {
+        hipLaunchKernelGGL(k_bbox, dim3(p.R * ((p.nblk + 3u) / 4u)), block, 0, st, p);
+        hipLaunchKernelGGL(k_gridp, dim3(p.R), dim3(GD_GRIDP_THREADS), 0, st, p);
+        hipLaunchKernelGGL((k_bin<false, false>), grid, block, 0, st, p);
     }
+    hipLaunchKernelGGL(k_scan, dim3(p.R, std::max(1u, p.scan_segments)), dim3(1024), 0, st, p);
+    if (p.periodic) { hipLaunchKernelGGL(k_members<true>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, st, p); }
+    else { hipLaunchKernelGGL(k_members<false>, grid, block, 0, st, p); hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, st, p); }
+    if (p.tiled && p.periodic) hipLaunchKernelGGL(k_tiles<true>, dim3((p.R * p.nblk + 63) / 64), dim3(64), 0, st, p);
+    else if (p.tiled) hipLaunchKernelGGL(k_tiles<false>, dim3((p.R * p.nblk + 63) / 64 + p.R), dim3(64), 0, st, p);
     if (p.tiled) {
         const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
-        const bool s16 = p.tile_cap < 4096u;                            // byte-offset entries, as k_step expects
-#define GD_FILL(PER, S, CNT) hipLaunchKernelGGL((k_fill<PER, true, S, CNT>), gridx, block, lds, st, p)
-        if (what == 1) {
-            if (p.periodic) { if (s16) GD_FILL(true, true, true); else GD_FILL(true, false, true); }
-            else { if (s16) GD_FILL(false, true, true); else GD_FILL(false, false, true); }
-        } else {
-            if (p.periodic) { if (s16) GD_FILL(true, true, false); else GD_FILL(true, false, false); }
-            else { if (s16) GD_FILL(false, true, false); else GD_FILL(false, false, false); }
-        }
-#undef GD_FILL
+        if (p.periodic) {
+            if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p);
+            else hipLaunchKernelGGL((k_fill<true, true, false>), gridx, block, lds, st, p);
+        } else if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<false, true, true>), gridx, block, lds, st, p);    // byte-offset entries, as k_step expects
+        else hipLaunchKernelGGL((k_fill<false, true, false>), gridx, block, lds, st, p);
     } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false, false>), gridx, block, 0, st, p);
     else hipLaunchKernelGGL((k_fill<false, false, false>), gridx, block, 0, st, p);
 }
@@ -2372,14 +2399,10 @@ hipError_t gd_kernels_init_device(void)
 #undef GD_AS_ALL
 #undef GD_AS_PK
 #undef GD_AS
-    set(reinterpret_cast<const void *>(&k_fill<false, true, false, false>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<false, true, true, false>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<true, true, false, false>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<true, true, true, false>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<false, true, false, true>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<false, true, true, true>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<true, true, false, true>), 128 * 1024);
-    set(reinterpret_cast<const void *>(&k_fill<true, true, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, false>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, true>), 128 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<0>), 64 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<1>), 64 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<2>), 64 * 1024);

@@ -279,15 +279,17 @@ struct BuildParams {
     // Ragged rows of the tiled lists.  The rows of one k_step wave (64 threads, ordered by list length: near-uniform lists) are as
     // wide as the wave's longest list needs; a build takes them from one pool (nbr16) with a bump cursor, one atomic per block.
     // The width has to be known before the first entry is written: it is PREDICTED from what each bead needed at the build before
-    // (need_prev, + an eighth and a chunk to spare per class); a bead that outgrows its wave's width flags GD_FLAG_OVERFLOW as a
-    // row overflow always did -- the chunk is rolled back and the next build is EXACT: a counting pass of k_fill first (tests only,
-    // no rows: it records every bead's need), the host sizes the pool from its total, then the filling pass with those needs.
+    // (need_prev, + an eighth and a chunk to spare per class; without history: p.W entries).  A list that outgrows its wave's rows
+    // is repaired inside k_fill: rows keep counting past their width, so the block's last wave to finish knows the exact need,
+    // takes fresh rows of that width from the pool and lists the 64 beads of that wave again (no rollback, no second launch).
+    // Only a FULL POOL is the host's business: GD_FLAG_OVERFLOW bit 4, the cursor keeps counting -- its final value is the need.
     uint2 *wtab;                        // [R * Np / 64] (first KiB, chunks per lane) per k_step wave
     unsigned short *need_prev;          // [R*N] by bead id: near chunks (10 bits) | far chunks << 10 (6 bits) the last build counted
-    unsigned *pool;                     // [0] cursor of the filling pass (KiB taken so far; its final value is the pool's use),
-                                        // [1] KiB a counting pass found the rows to need; both zeroed by k_scan
+    unsigned *pool;                     // [0] cursor (KiB taken so far; its final value is the pool's use, or the need when it was full; k_scan
+                                        // starts it over), [1] the largest final value of the builds before this one, [2] k_step waves
+                                        // repaired -- [1] and [2] since the host last cleared them (with the flags)
     unsigned pool_cap;                  // KiB of the pool
-    int exact;                          // need_prev holds the needs of THIS build (a counting pass ran): no slack
+    int predict;                        // 1: need_prev describes these beads (the build before ran at this radius and class mode)
     unsigned long long *dbg;            // section stamps of timing-only builds (the force-output buffer)
 };
 
@@ -295,8 +297,7 @@ struct BuildParams {
 hipError_t gd_kernels_init_device(void);      // LDS opt-in of every kernel that needs it, on the current device (once per device: gd_create)
 void gd_launch_step(const StepParams &p, int mode, hipStream_t st);
 void gd_launch_finalize(const StepParams &p, int mode, hipStream_t st);     // k_ctx: 0 final callback, 1 fold reaction partials
-// what: 0 the whole chain with the filling pass; 1 the chain with the counting pass of k_fill (tiled lists); 2 the filling pass alone
-void gd_launch_build(const BuildParams &p, hipStream_t st, int what = 0);
+void gd_launch_build(const BuildParams &p, hipStream_t st);
 // Droplet attraction among a small set of target beads (gd_set_pair_softwell): all pairs, one thread per target.
 struct SoftwellP {
     const float4 *pos_in;       // positions the forces are evaluated on (slot order)

@@ -33,5 +33,6 @@ def oracle(gdyn):
 
 @pytest.fixture(scope="session")
 def hip(gdyn):
-    """The product library; GPU tests fail loudly if it is not built."""
-    return gdyn.load()
+    """The product library; GPU tests fail loudly if it is not built.  (GDYN_TEST_LIB: a developer build of csrc/ instead -- the
+    test harness reads it, the package does not.)"""
+    return gdyn.load(os.environ.get("GDYN_TEST_LIB") or None)
