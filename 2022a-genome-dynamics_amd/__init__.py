@@ -26,7 +26,7 @@ POT_HARMONIC, POT_SPRING, POT_SEMISPRING, POT_SOFTCORE = 0, 1, 2, 3
 NOISE_PHILOX, NOISE_ZERO, NOISE_HOST, NOISE_MT19937 = 0, 1, 2, 3
 RUN_UPDATE_SCALES, RUN_WALL_DYNAMICS, RUN_DEFER_CALLBACK, RUN_COMPENSATED, RUN_UNCOMPENSATED = 1, 2, 4, 8, 16
 ALL_REPLICAS = 0xffffffff
-ABI_VERSION = 4            # GD_ABI_VERSION of the include/gdyn.h these ctypes structures mirror
+ABI_VERSION = 5            # GD_ABI_VERSION of the include/gdyn.h these ctypes structures mirror
 TERM_PAIR, TERM_BOND, TERM_BEND, TERM_POINT, TERM_WALL, TERM_DYNAMIC, TERM_ALL = 1, 2, 4, 8, 16, 32, 63
 
 _STATUS = {1: "GD_EINVAL", 2: "GD_ENODEVICE", 3: "GD_EHIP", 4: "GD_ENOMEM", 5: "GD_ESTATE", 6: "GD_EUNSUPPORTED"}
@@ -68,7 +68,8 @@ class Context(C.Structure):
                 ("semiaxes", C.c_double * 3), ("axial_reaction", C.c_double * 3),
                 ("list_entries", C.c_uint64), ("rebuilds", C.c_uint64), ("rollbacks", C.c_uint64),
                 ("rebuild_interval", C.c_uint32), ("list_radius", C.c_double), ("list_path", C.c_uint32),
-                ("callback_pending", C.c_uint32), ("tile_capacity", C.c_uint32), ("compensated", C.c_uint32), ("largest_tile", C.c_uint32)]
+                ("callback_pending", C.c_uint32), ("tile_capacity", C.c_uint32), ("compensated", C.c_uint32), ("largest_tile", C.c_uint32),
+                ("row_repairs", C.c_uint32), ("near_entries", C.c_uint64), ("list_bytes", C.c_uint64)]
 
 
 class _RunDesc(C.Structure):

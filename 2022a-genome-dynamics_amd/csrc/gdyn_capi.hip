@@ -159,7 +159,7 @@ struct gd_system {
     DevBuf<float4> rec_x0; DevBuf<uint2> rec_mo; DevBuf<unsigned char> len_prev;
     // Ragged rows of the tiled lists (BuildParams): per-wave row table, what every bead needed at the last build, the pool's cursor.
     // nbr16 IS the pool: pool KiB = nbr16.n / 512 entries.
-    DevBuf<uint2> wtab; DevBuf<unsigned short> need_prev; DevBuf<unsigned> pool;
+    DevBuf<uint2> wtab, rqueue; DevBuf<unsigned short> need_prev; DevBuf<unsigned> pool;
     bool need_valid = false;       // need_prev describes the state about to be listed well enough to predict row widths from it
     float need_rv = 0; bool need_all_near = false;      // list radius / class mode need_prev was counted at
     uint32_t pool_used = 0;        // KiB the last build took (its cursor's final value: the need, when the pool was full)
@@ -251,7 +251,7 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
     s->a.assign(s->N, 0.0); s->b.assign(s->N, 0.0); s->mob.assign(s->N, 1.0); s->bend.assign(s->N, 0.0);
     s->hctx.assign(s->R, DevCtx{});
     for (auto &c : s->hctx) { c.bead_scale = 1; c.bond_scale = 1; }   // wall_semiaxes {0,0,0} until a wall is set (simulation_context.hpp:16)
-    s->lcount.assign(s->R, 0ull);
+    s->lcount.assign(2 * (size_t)s->R, 0ull);      // per replica: directed entries, then the near entries (in fours) of tiled lists
     s->ncell_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8ull * s->N, 4096ull), 262144ull);
     if (const char *e = dev_env("GDYN_NEAR_FRAC")) s->near_frac = atof(e);
     if (const char *e = dev_env("GDYN_SKIN")) { s->skin = atof(e); s->skin_fixed = true; }
@@ -270,10 +270,10 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
          s->flags.resize((size_t)s->R * GD_NFLAGS) == hipSuccess && s->bbox.resize((size_t)s->R * s->nblk * 6) == hipSuccess &&
          s->ab.resize(RNp) == hipSuccess && s->mobs.resize(RNp) == hipSuccess && s->grid.resize(s->R) == hipSuccess &&
          s->epart.resize((size_t)s->R * s->nblk) == hipSuccess &&
-         s->lcount_d.resize(s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
+         s->lcount_d.resize(2 * (size_t)s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess &&
-         s->wtab.resize(RNp / 64) == hipSuccess && s->need_prev.resize((size_t)s->R * s->N) == hipSuccess && s->pool.resize(4) == hipSuccess &&
+         s->wtab.resize(RNp / 64) == hipSuccess && s->need_prev.resize((size_t)s->R * s->N) == hipSuccess && s->pool.resize(4) == hipSuccess && s->rqueue.resize(GD_REPAIR_QUEUE) == hipSuccess &&
          s->lo.resize(RN) == hipSuccess;
     s->lo_valid = ok;      // (positions and residuals all zero)
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
@@ -561,6 +561,9 @@ extern "C" int gd_get_context(gd_system *s, uint32_t r, gd_context *o)
     o->tile_capacity = (s->list_valid && s->list_tiled) ? s->list_tile_cap : 0u;
     o->compensated = s->comp_last ? 1u : 0u;
     o->largest_tile = (s->list_valid && s->list_tiled) ? s->last_need_t : 0u;
+    o->row_repairs = s->list_tiled ? s->repairs : 0u;
+    o->near_entries = s->list_tiled ? s->lcount[(size_t)s->R + r] : 0ull;
+    o->list_bytes = !s->list_valid ? 0ull : s->list_tiled ? 1024ull * s->pool_used : (uint64_t)s->list_W * s->R * s->Np * 4ull;
     return GD_OK;
 }
 
@@ -863,7 +866,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.w_valid = (s->packed_ab && s->w_packed) ? 1 : 0;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
-    b.wtab = s->wtab.p; b.need_prev = s->need_prev.p; b.pool = s->pool.p;
+    b.wtab = s->wtab.p; b.need_prev = s->need_prev.p; b.pool = s->pool.p; b.rqueue = s->rqueue.p; b.rq_cap = GD_REPAIR_QUEUE;
     if (tiled) {
         // Ragged rows (BuildParams): every k_step wave's rows are as wide as its longest list, predicted from what each bead needed at
         // the build before (no history -- first build, positions from the caller, another list radius or class mode: W entries per
@@ -878,6 +881,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
         if (pool_kib() < want || pool_kib() > 2 * want + 4 * waves) HIPCHK(s->nbr16.resize((want + want / 16) * 512, false));      // (not preserved: the list in it is about to be rebuilt)
         if (dev_env("GDYN_DEBUG") && dev_env("GDYN_DEBUG")[0] == '2')
             fprintf(stderr, "[gdyn] build %llu: %s, rows used %u KiB, pool %zu KiB, rv %.4f\n", (unsigned long long)s->rebuilds, predict ? "predicted" : "no history", s->pool_used, pool_kib(), rv);
+        if (!predict) s->pool_used = (uint32_t)std::min<size_t>(used, 0xffffffffu);      // (the guess stands in until a chunk's readback brings the real use)
         b.predict = predict ? 1 : 0; b.nbr16 = s->nbr16.p; b.pool_cap = (unsigned)std::min<size_t>(pool_kib(), 0xffffffffu);
         s->need_valid = true; s->need_rv = rv; s->need_all_near = s->all_near;
     }
@@ -1057,7 +1061,7 @@ static int build_now(gd_system *s, float rv, bool with_list, bool allow_tiled = 
         std::vector<unsigned> f;
         GDCHK(read_flags(s, f));
         if (!handle_overflow(s, f)) {
-            HIPCHK(hipMemcpy(s->lcount.data(), s->lcount_d.p, s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(s->lcount.data(), s->lcount_d.p, 2 * (size_t)s->R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             GDCHK(clear_flags(s));
             return GD_OK;
         }
@@ -1425,7 +1429,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         std::vector<DevCtx> ctx_new(s->R);
         HIPCHK(hipGetLastError());
         {
-            const size_t nf = f.size() * sizeof(unsigned), nc = s->R * sizeof(DevCtx), nl = s->R * sizeof(unsigned long long), nd = s->R * sizeof(float);
+            const size_t nf = f.size() * sizeof(unsigned), nc = s->R * sizeof(DevCtx), nl = 2 * (size_t)s->R * sizeof(unsigned long long), nd = s->R * sizeof(float);
             if (!s->h_chunk) HIPCHK(hipHostMalloc((void **)&s->h_chunk, nf + nc + nl + nd + 16, hipHostMallocDefault));
             HIPCHK(hipMemcpyAsync(s->h_chunk + nf + nc + nl + nd, s->pool.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));      // the row pool's use
             HIPCHK(hipMemcpyAsync(s->h_chunk, s->flags.p, nf, hipMemcpyDeviceToHost, s->stream));
@@ -1492,7 +1496,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         s->timing.total_ms += ms; s->timing.step_kernel_ms += step_ms; s->timing.rebuild_ms += build_ms;
         s->hctx = ctx_new;
         unsigned long long L = 0;
-        for (auto v : s->lcount) L += v;
+        for (uint32_t r = 0; r < s->R; r++) L += s->lcount[r];
         s->timing.list_entries_visited += L * (uint64_t)chunk;   // L of the last build, per step
         if (s->adapt && with_list && full_interval && !on_search_list) {
             const double cut_now = pair_cutoff(s) * (s->pair.scale_by_bead_scale ? bead_scale_bound(s, nullptr, 0) : 1.0);

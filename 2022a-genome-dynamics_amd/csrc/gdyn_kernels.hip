@@ -1282,8 +1282,8 @@ __global__ __launch_bounds__(1024) void k_scan(const BuildParams p)
     const unsigned n = (unsigned)p.grid[r].ncell;
     unsigned t0 = blockIdx.y * GD_SCAN_TILE;
     if (blockIdx.y == 0 && tid == 1023) {      // the per-build words of the replica start over (the last wave: off the path of the scan)
-        p.lcount[r] = 0ull;
-        if (r == 0 && p.pool) { p.pool[1] = max(p.pool[1], p.pool[0]); p.pool[0] = 0u; }      // the row pool's cursor starts over; [1] keeps the largest use since the host looked (BuildParams)
+        p.lcount[r] = 0ull; p.lcount[p.R + r] = 0ull;
+        if (r == 0 && p.pool) { p.pool[1] = max(p.pool[1], p.pool[0]); p.pool[0] = 0u; p.pool[3] = 0u; }      // the row pool's cursor starts over; [1] keeps the largest use since the host looked (BuildParams)
         p.dmax[r * GD_DMAX_STRIDE] = 0u;        // largest squared displacement since this build (k_step keeps it current)
         if (p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW] | p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW]) p.flags[r * GD_NFLAGS + GD_FLAG_TAINT] = 1u;
     }
@@ -1581,9 +1581,17 @@ __global__ __launch_bounds__(GD_BLOCK) void k_scatter(const BuildParams p)
 
 // Per new slot: re-map the bonded topology to slots and fill the Verlet list (27-cell sweep).
 // TILED: candidates are read from the block's LDS tile and list entries are tile indices.
-template <bool PERIODIC, bool TILED, bool S16>
-__global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
+// (register budget of the tiled variants: 6 waves per SIMD = three blocks per CU = at most 80 VGPRs for open boxes, as the LDS admits
+// with the 3 312-entry tile class; the periodic sweep holds 18 window bounds: 4 waves per SIMD = two blocks = 128)
+// REPAIR (tiled lists; launched behind the build's k_fill with blocks of ONE wave): the rows of a k_step wave in which some list outgrew
+// the predicted width are written again at the width they turned out to need -- the block's tile staged again, the 64 beads of
+// that wave listed by the 64 lanes, fresh rows from the pool; the queue of such waves is filled by the last wave of every k_fill
+// block (below) and is empty in almost every build.
+template <bool PERIODIC, bool TILED, bool S16, bool REPAIR = false>
+__global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERIODIC ? 4 : 6) : 1)) void k_fill(const BuildParams p)
 {
+    static_assert(TILED || !REPAIR, "only the ragged rows of the tiled lists are repaired");
+    constexpr unsigned NTHR = REPAIR ? 64u : (unsigned)GD_BLOCK;
     GD_FSTAMP_BEGIN();
     extern __shared__ __attribute__((aligned(16))) float4 s_tile[];
     // block totals (list entries, longest list): accumulated by LDS atomics as the waves finish; the last one to finish hands them on --
@@ -1593,14 +1601,18 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     __shared__ unsigned s_acc_max, s_acc_done;
     // ragged rows: chunks per lane and first KiB of the rows of each of the block's eight k_step waves
     __shared__ unsigned s_wn[GD_BLOCK / 64], s_woff[GD_BLOCK / 64], s_wneed[GD_BLOCK / 64];      // (s_wneed: what the lists turned out to need)
-    unsigned r, blk;
-    if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
+    unsigned r, blk, rep_w = 0, rep_need = 0;
+    if (REPAIR) {
+        if (blockIdx.x >= min(p.pool[3], p.rq_cap)) return;      // (queue items; one block = one wave each)
+        const uint2 item = p.rqueue[blockIdx.x];
+        r = (item.x >> 3) / p.nblk; blk = (item.x >> 3) % p.nblk; rep_w = item.x & 7u; rep_need = item.y;
+    } else if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_acc_cnt = 0ull; s_acc_max = 0u; s_acc_done = 0u; }
     if (threadIdx.x < GD_BLOCK / 64) { s_wn[threadIdx.x] = 0u; s_woff[threadIdx.x] = 0u; s_wneed[threadIdx.x] = 0u; }
     if (!TILED) __syncthreads();      // (the tiled path has its barriers below)
     const size_t rbase = (size_t)r * p.Np;
-    unsigned slot = blk * GD_BLOCK + threadIdx.x;      // (slot, gt, o, wk: the thread's own bead -- in the repair pass of a block's last wave, below, another one)
+    unsigned slot = blk * GD_BLOCK + threadIdx.x;      // (REPAIR: set below, from the record of the k_step thread this lane stands for)
     size_t gt = rbase + slot;
     const size_t g = rbase + slot;
     const float4 *__restrict__ rpos = p.pos_out + rbase;
@@ -1612,7 +1624,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     // store), so it is copied once into LDS (188 bytes) and read from there.
     __shared__ TileDesc s_tdesc;
 #define s_td s_tdesc
-    const unsigned o_pre = (TILED && slot < p.N) ? p.orig_out[g] : 0u;      // (issued ahead of the DMAs: the balancing key below depends on it)
+    const unsigned o_pre = (TILED && !REPAIR && slot < p.N) ? p.orig_out[g] : 0u;      // (issued ahead of the DMAs: the balancing key below depends on it)
     if (TILED) {
         // LDS-DMA staging as in k_step: descriptor by scalar loads first, then all pieces back to back
         unsigned tlen[GD_TILE_RANGES], tst[GD_TILE_RANGES], tbase[GD_TILE_RANGES];
@@ -1622,7 +1634,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
 #pragma unroll
         for (int k = 0; k < GD_TILE_RANGES; k++) {
             const unsigned len = tlen[k], st = tst[k], base = tbase[k];
-            for (unsigned q0 = wq; q0 < len; q0 += GD_BLOCK) {
+            for (unsigned q0 = wq; q0 < len; q0 += NTHR) {
                 if (q0 + lane < len)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rpos + st + q0 + lane),
                                                      (__attribute__((address_space(3))) void *)(s_tile + base + q0), 16, 0, 0);
@@ -1634,7 +1646,21 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     // batches.  This kernel still works slot by slot (neighbouring slots share their row windows: broadcast LDS reads, equal
     // trip counts), but writes each bead's list, adjacency chunks and record at the position gt of the k_step thread
     // that will own it.
-    if (TILED) {
+    if (TILED && REPAIR) {
+        if (threadIdx.x < sizeof(TileDesc) / 4) ((unsigned *)&s_tdesc)[threadIdx.x] = ((const unsigned *)tdp)[threadIdx.x];
+        __syncthreads();      // (also waits for the tile DMAs)
+        if (PERIODIC) {       // the wrapped tile, as below
+            const unsigned total = s_tdesc.total;
+            for (unsigned t = threadIdx.x; t < total; t += NTHR) {
+                float4 x = s_tile[t];
+                x.x -= p.box[0] * floorf(x.x * p.inv_box[0]); x.y -= p.box[1] * floorf(x.y * p.inv_box[1]); x.z -= p.box[2] * floorf(x.z * p.inv_box[2]);
+                s_tile[t] = x;
+            }
+            __syncthreads();
+        }
+        gt = rbase + (size_t)blk * GD_BLOCK + rep_w * 64u + lane;
+    }
+    if (TILED && !REPAIR) {
         // (two barriers: histogram cleared + descriptor copied | histogram complete; every wave then scans the 64 bins itself.
         // The first barrier also waits for the tile DMAs issued above.)
         // (the order is STABLE -- by bin, then by slot: ranks handed out by an LDS atomic would be arrival orders, and the thread a bead
@@ -1688,8 +1714,22 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
     // bead needed at the build before plus an eighth and a chunk per class (no history: the caller's guess, p.W entries); at least one
     // chunk, so that k_step's unconditional first chunk load stays inside the pool.  A list that outgrows its row is REPAIRED at the
     // end of the kernel (no rollback): see the repair pass below.
-    unsigned wk = TILED ? ((unsigned)(gt - rbase) - blk * GD_BLOCK) >> 6 : 0u;
-    if (TILED) {
+    const unsigned wk = TILED ? ((unsigned)(gt - rbase) - blk * GD_BLOCK) >> 6 : 0u;
+    unsigned row_nc = 0u, row_off = 0u;
+    if (TILED && REPAIR) {      // fresh rows of the width the wave's lists need
+        unsigned off = 0u;
+        if (lane == 0) {
+            off = atomicAdd(&p.pool[0], rep_need);
+            if (!(off <= p.pool_cap && rep_need <= p.pool_cap - off)) {
+                if (!p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);
+                off = 0xffffffffu;
+            } else p.wtab[(rbase + (size_t)blk * GD_BLOCK) / 64 + rep_w] = make_uint2(off, rep_need);
+        }
+        off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+        if (off == 0xffffffffu) return;      // (the pool is full: the rows stay as they are, flagged)
+        row_off = off; row_nc = rep_need;
+    }
+    if (TILED && !REPAIR) {
         unsigned want = 1u;
         if (slot < p.N) {
             if (p.predict) {
@@ -1720,7 +1760,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         // (the cursor's answer is needed behind the re-map of the bonded topology below: a barrier there, not here)
     }
     GD_FSTAMP(0);     // staging + barrier
-    unsigned cnt = 0;
+    unsigned cnt = 0, near4 = 0;
     unsigned o = 0, deg = 0;
     const unsigned nr_tile = TILED ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_td.nranges) : 0u;      // (merged ranges in use: three, typically)
     auto to_local = [&](unsigned ps, unsigned &idx) -> bool {   // slot -> tile index
@@ -1730,12 +1770,17 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         }
         return false;
     };
-    size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
-    if (slot < p.N) {
+    const size_t gw = TILED ? gt : g;          // where this thread's chunks and records go
+    bool on = slot < p.N;
+    if (REPAIR) {
+        const uint2 mo = p.rec_mo[gt];
+        on = mo.y != GD_REC_NOBEAD;
+        slot = blk * GD_BLOCK + ((mo.x >> 12) & 0x1ffu); o = mo.y & GD_REC_ID_MASK; deg = mo.x & 0xffu;
+    } else if (on) {
         o = p.orig_out[g];
         deg = p.bdeg_o[o];
     }
-    if (slot < p.N) {
+    if (!REPAIR && on) {
         const unsigned *so = p.slot_of + (size_t)r * p.N;
         uint4 *__restrict__ adjw = (uint4 *)p.badj + (size_t)(gw >> 6) * (p.WB / 4) * 64 + (gw & 63);
         // one 16-byte adjacency chunk per round: its four gathers (entry by bead, then slot by partner) are in flight
@@ -1768,15 +1813,10 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
         }
     }
     GD_FSTAMP(1);     // bond / chain re-map
-    if (TILED) __syncthreads();      // the rows of the block's waves have their place (s_woff, s_wn)
-    // The sweep.  Pass 0: every thread lists its own bead.  Tiled lists, rarely: pass 1, 2, ... -- the block's LAST wave to finish repairs
-    // the rows of a k_step wave in which some list outgrew the predicted width (rows keep counting past their width, so the exact need
-    // is known): fresh rows of that width from the pool, the 64 beads of the wave listed again by the 64 lanes.  No barrier, no
-    // rollback; the abandoned rows stay in the pool until the next build.
-    bool on = slot < p.N;
-    unsigned row_nc = TILED ? s_wn[wk] : 0u, row_off = TILED ? s_woff[wk] : 0u, repaired = 0u;
-    for (unsigned pass = 0;; pass++) {
-    if (pass != 0) cnt = 0;
+    if (TILED && !REPAIR) {
+        __syncthreads();      // the rows of the block's waves have their place (s_woff, s_wn)
+        row_nc = s_wn[wk]; row_off = s_woff[wk];
+    }
     if (on) {
         unsigned listlen = 0, nAq = 0, nB = 0;
         if (!(p.nbr || p.nbr16)) {      // (a sort without lists: the counter of the bead's cell still goes back to zero, see below)
@@ -1804,8 +1844,13 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             // reads (8 x u16 tiled, 4 x u32 generic); a bead's 8 (4) consecutive entries share one chunk.
             constexpr unsigned PER = TILED ? 8u : 4u;
             // (tiled: the rows of the thread's k_step wave -- NC chunks per lane from KiB s_woff[wk] of the pool; generic: uniform rows)
-            const unsigned NC = TILED ? row_nc : p.W / PER;
-            uint4 *__restrict__ lst = TILED ? (uint4 *)p.nbr16 + ((size_t)row_off * 64 + (gw & 63)) : (uint4 *)p.nbr + (size_t)(gw >> 6) * NC * 64 + (gw & 63);
+            // (tiled: the width is a per-lane value now, and the sweep below sits exactly at its register budget -- 80 VGPRs for three
+            // blocks per CU: the width, the k_step wave and the bond degree share one register through the sweep and are unpacked
+            // where they are needed, a few times per bead; the empty asm keeps the unpacking from being hoisted back out)
+            unsigned pk = deg | (wk << 8) | (row_nc << 11);
+            auto NCf = [&]() -> unsigned { if (!TILED) return p.W / PER; unsigned t = pk; asm volatile("" : "+v"(t)); return t >> 11; };
+#define NC NCf()
+            uint4 *__restrict__ lst = TILED ? (uint4 *)p.nbr16 + ((size_t)row_off * 64 + (gw & 63)) : (uint4 *)p.nbr + (size_t)(gw >> 6) * (p.W / PER) * 64 + (gw & 63);
             // the 16-byte chunk under construction lives in four registers (an LDS staging slot per thread would cost
             // the 8 KB that separate two from three resident blocks per CU); every PER-th entry the finished chunk
             // goes out as one 16-byte global store (2-byte scattered global stores were 25% of the build)
@@ -1836,7 +1881,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 b0 = __builtin_amdgcn_alignbit(b1, b0, 16); b1 = __builtin_amdgcn_alignbit(b2, b1, 16);
                 b2 = __builtin_amdgcn_alignbit(b3, b2, 16); b3 = __builtin_amdgcn_alignbit(j, b3, 16);
                 cntB++;
-                if (cntB % 8u == 0) { if (cntB / 8u <= NC) lst[(size_t)(NC - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3); }
+                if (cntB % 8u == 0) { const unsigned nc = NC; if (cntB / 8u <= nc) lst[(size_t)(nc - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3); }
             };
             if (TILED && PERIODIC) {
                 // periodic tile = whole rows: for each of the 9 wrapped (dz,dy) rows the x-window cx-1..cx+1 is one slot interval, or
@@ -2007,7 +2052,7 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             const bool class_over = TILED && (needA > GD_TILED_MAX_NEAR || needB > GD_TILED_MAX_FAR);
             // (tiled lists: a row that is too narrow is repaired below, only a class beyond its field is flagged; generic lists: the
             // host widens the uniform rows and builds again)
-            const unsigned Wrow = NC * PER;
+            const unsigned nc_row = NC, Wrow = nc_row * PER;
             if (((!TILED && needw > Wrow) || class_over) && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) {
                 atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], class_over ? 3u : 1u);
                 atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], needw);
@@ -2017,16 +2062,48 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
                 // the sum for its longest list
                 const unsigned na8 = min(needA / 8u, GD_TILED_MAX_NEAR / 8u), nb8 = min(needB / 8u, GD_TILED_MAX_FAR / 8u);
                 p.need_prev[(size_t)r * p.N + o] = (unsigned short)(na8 | (nb8 << 10));
-                if (pass == 0) atomicMax(&s_wneed[wk], na8 + nb8);
+                if (!REPAIR) atomicMax(&s_wneed[(pk >> 8) & 7u], na8 + nb8);
             }
             listlen = min(found, Wrow);
             nAq = min((cnt + 3u) / 4u, GD_TILED_MAX_NEAR / 4u);            // near entries in fours (the record's count; chunks are still written whole)
-            while (cnt % GD_UNROLL) push(self);
+            // pad the chunk under construction with the bead itself: the shift register moves down by the missing entries in three
+            // branch-free stages (four, two, one entry -- a loop of single pushes ran seven times in nearly every wave, 16 instructions
+            // each) and goes out with one store
             flush();
-            if (TILED) while (cntB % GD_UNROLL) push_far(self);
+            auto pad = [&](unsigned &a0, unsigned &a1, unsigned &a2, unsigned &a3, unsigned sh) {      // sh entries (< PER) of `self` in from the top
+                const unsigned S = TILED ? self | (self << 16) : self;
+                if (TILED) {
+                    const bool s4 = (sh & 4u) != 0u, s2 = (sh & 2u) != 0u, s1 = (sh & 1u) != 0u;
+                    a0 = s4 ? a2 : a0; a1 = s4 ? a3 : a1; a2 = s4 ? S : a2; a3 = s4 ? S : a3;
+                    a0 = s2 ? a1 : a0; a1 = s2 ? a2 : a1; a2 = s2 ? a3 : a2; a3 = s2 ? S : a3;
+                    const unsigned c0 = __builtin_amdgcn_alignbit(a1, a0, 16), c1 = __builtin_amdgcn_alignbit(a2, a1, 16),
+                                   c2 = __builtin_amdgcn_alignbit(a3, a2, 16), c3 = __builtin_amdgcn_alignbit(S, a3, 16);
+                    a0 = s1 ? c0 : a0; a1 = s1 ? c1 : a1; a2 = s1 ? c2 : a2; a3 = s1 ? c3 : a3;
+                } else {
+                    const bool s2 = (sh & 2u) != 0u, s1 = (sh & 1u) != 0u;
+                    a0 = s2 ? a2 : a0; a1 = s2 ? a3 : a1; a2 = s2 ? S : a2; a3 = s2 ? S : a3;
+                    a0 = s1 ? a1 : a0; a1 = s1 ? a2 : a1; a2 = s1 ? a3 : a2; a3 = s1 ? S : a3;
+                }
+            };
+            if (cnt % PER) {
+                pad(w0, w1, w2, w3, PER - cnt % PER);
+                cnt = (cnt + PER - 1u) & ~(PER - 1u);
+                if (cnt / PER <= nc_row) lst[(size_t)(cnt / PER - 1u) * 64] = make_uint4(w0, w1, w2, w3);
+            }
+            if (!TILED && cnt % GD_UNROLL) {      // (generic lists are walked in batches of two chunks: a whole chunk of the bead itself behind an odd one)
+                cnt += PER;
+                if (cnt / PER <= nc_row) lst[(size_t)(cnt / PER - 1u) * 64] = make_uint4(self, self, self, self);
+            }
+            if (TILED && cntB % 8u) {
+                pad(b0, b1, b2, b3, 8u - cntB % 8u);
+                cntB = (cntB + 7u) & ~7u;
+                if (cntB / 8u <= nc_row) lst[(size_t)(nc_row - cntB / 8u) * 64] = make_uint4(b0, b1, b2, b3);
+            }
             // (an overflowed list: the chunk counts have to stay inside the row until it is repaired)
-            nAq = min(nAq, 2u * NC); nB = min(min(cntB / GD_UNROLL, GD_TILED_MAX_FAR / GD_UNROLL), NC - (nAq + 1u) / 2u);
-            cnt = found;
+            nAq = min(nAq, 2u * nc_row); nB = min(min(cntB / GD_UNROLL, GD_TILED_MAX_FAR / GD_UNROLL), nc_row - (nAq + 1u) / 2u);
+            cnt = found; near4 = 4u * nAq;
+            deg = pk & 0xffu;
+#undef NC
         }
         const unsigned meta = deg | ((unsigned)p.psmask_o[o] << 8) | (listlen << 16);
         if (TILED) {
@@ -2038,58 +2115,38 @@ __global__ __launch_bounds__(GD_BLOCK) void k_fill(const BuildParams p)
             p.len_prev[(size_t)r * p.N + o] = (unsigned char)min(nAq, 255u);       // (the near class is what most steps run over)
         } else p.meta[g] = meta;
     }
-    if (pass == 0) {
-        if (TILED && !on) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
-        GD_FSTAMP(5);     // padding, meta
-        unsigned long long c64 = cnt;
-        unsigned cmax = cnt;
-        for (int o2 = 32; o2 > 0; o2 >>= 1) { c64 += __shfl_xor(c64, o2, 64); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o2, 64)); }
-        unsigned last = 0u;
-        if (lane == 0) {
-            atomicAdd(&s_acc_cnt, c64); atomicMax(&s_acc_max, cmax);
-            __threadfence_block();       // (this wave's records and needs are written before it counts as done)
-            if (atomicAdd(&s_acc_done, 1u) == GD_BLOCK / 64 - 1u) {      // the last wave of the block to finish
-                __threadfence_block();
-                const unsigned long long t = atomicAdd(&s_acc_cnt, 0ull);
-                const unsigned m = atomicMax(&s_acc_max, 0u);
-                if (t) atomicAdd(&p.lcount[r], t);
-                if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always
-                last = 1u;
+    if (REPAIR) return;
+    if (TILED && !on) { p.rec_x0[gt] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffu)); p.rec_mo[gt] = make_uint2(0u, GD_REC_NOBEAD); }
+    GD_FSTAMP(5);     // padding, meta
+    // (per block both counts fit 32 bits: the entries in the low word, the near entries -- in the fours k_step walks -- in the high one)
+    unsigned long long c64 = (unsigned long long)cnt | ((unsigned long long)near4 << 32);
+    unsigned cmax = cnt;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { c64 += __shfl_xor(c64, o2, 64); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o2, 64)); }
+    if (lane == 0) {
+        atomicAdd(&s_acc_cnt, c64); atomicMax(&s_acc_max, cmax);
+        __threadfence_block();       // (this wave's needs are in LDS before it counts as done)
+        if (atomicAdd(&s_acc_done, 1u) == GD_BLOCK / 64 - 1u) {      // the last wave of the block to finish
+            __threadfence_block();
+            const unsigned long long t = atomicAdd(&s_acc_cnt, 0ull);
+            const unsigned m = atomicMax(&s_acc_max, 0u);
+            if (t) { atomicAdd(&p.lcount[r], t & 0xffffffffull); if (TILED) atomicAdd(&p.lcount[p.R + r], t >> 32); }
+            if (m && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_W], m);      // longest list, always
+            // k_step waves of this block whose lists outgrew their rows: queued for the repair kernel (a block without rows -- the
+            // pool was full -- is not repaired: flagged above, the host enlarges the pool)
+            if (TILED) {
+                for (unsigned w = 0; w < GD_BLOCK / 64; w++) {
+                    const unsigned need = atomicMax(&s_wneed[w], 0u), have = s_wn[w];
+                    if (have != 0u && need > have) {
+                        const unsigned at = atomicAdd(&p.pool[3], 1u);
+                        if (at < p.rq_cap) p.rqueue[at] = make_uint2(((r * p.nblk + blk) << 3) | w, need);
+                        else if (!p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);      // (more than the queue holds: the chunk is rolled back, the next build predicts from these needs)
+                        atomicAdd(&p.pool[2], 1u);      // (repaired waves: diagnostics)
+                    }
+                }
             }
         }
-        GD_FSTAMP(6);     // count
-        if (!TILED || !__builtin_amdgcn_readfirstlane((int)last)) break;
-        __threadfence_block();
     }
-    // the last wave: the next k_step wave of the block whose lists outgrew their rows (a block without rows -- the pool was full -- is
-    // not repaired: flagged above, the host enlarges the pool)
-    unsigned w = GD_BLOCK / 64;
-    for (unsigned q = 0; q < GD_BLOCK / 64; q++)
-        if (w == GD_BLOCK / 64 && !((repaired >> q) & 1u) && s_wn[q] != 0u && atomicMax(&s_wneed[q], 0u) > s_wn[q]) w = q;
-    if (w == GD_BLOCK / 64) break;
-    repaired |= 1u << w;
-    const unsigned need = max(atomicMax(&s_wneed[w], 0u), 1u);
-    unsigned off = 0u;
-    if (lane == 0) {
-        off = atomicAdd(&p.pool[0], need);
-        if (!(off <= p.pool_cap && need <= p.pool_cap - off)) {
-            if (!p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);
-            off = 0xffffffffu;
-        } else {
-            p.wtab[(rbase + (size_t)blk * GD_BLOCK) / 64 + w] = make_uint2(off, need);
-            atomicAdd(&p.pool[2], 1u);      // (repaired waves of this build: diagnostics)
-        }
-    }
-    off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
-    if (off == 0xffffffffu) break;      // (the pool is full: the rows stay as they are, flagged)
-    row_off = off; row_nc = need; wk = w;
-    gt = rbase + (size_t)blk * GD_BLOCK + w * 64u + lane; gw = gt;
-    {
-        const uint2 mo = p.rec_mo[gt];
-        on = mo.y != GD_REC_NOBEAD;
-        slot = blk * GD_BLOCK + ((mo.x >> 12) & 0x1ffu); o = mo.y & GD_REC_ID_MASK; deg = mo.x & 0xffu;
-    }
-    }
+    GD_FSTAMP(6);     // count
     GD_FSTAMP_END(p.dbg);
 }
 
@@ -2115,11 +2172,14 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
     else if (p.tiled) hipLaunchKernelGGL(k_tiles<false>, dim3((p.R * p.nblk + 63) / 64 + p.R), dim3(64), 0, st, p);
     if (p.tiled) {
         const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
+        // (behind it the repair kernel: one wave per queued k_step wave; its blocks leave at once while the queue is empty)
+        const dim3 gridr(p.rq_cap), blockr(64);
         if (p.periodic) {
-            if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p);
-            else hipLaunchKernelGGL((k_fill<true, true, false>), gridx, block, lds, st, p);
-        } else if (p.tile_cap < 4096u) hipLaunchKernelGGL((k_fill<false, true, true>), gridx, block, lds, st, p);    // byte-offset entries, as k_step expects
-        else hipLaunchKernelGGL((k_fill<false, true, false>), gridx, block, lds, st, p);
+            if (p.tile_cap < 4096u) { hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p); hipLaunchKernelGGL((k_fill<true, true, true, true>), gridr, blockr, lds, st, p); }
+            else { hipLaunchKernelGGL((k_fill<true, true, false>), gridx, block, lds, st, p); hipLaunchKernelGGL((k_fill<true, true, false, true>), gridr, blockr, lds, st, p); }
+        } else if (p.tile_cap < 4096u) {      // byte-offset entries, as k_step expects
+            hipLaunchKernelGGL((k_fill<false, true, true>), gridx, block, lds, st, p); hipLaunchKernelGGL((k_fill<false, true, true, true>), gridr, blockr, lds, st, p);
+        } else { hipLaunchKernelGGL((k_fill<false, true, false>), gridx, block, lds, st, p); hipLaunchKernelGGL((k_fill<false, true, false, true>), gridr, blockr, lds, st, p); }
     } else if (p.periodic) hipLaunchKernelGGL((k_fill<true, false, false>), gridx, block, 0, st, p);
     else hipLaunchKernelGGL((k_fill<false, false, false>), gridx, block, 0, st, p);
 }
@@ -2403,6 +2463,10 @@ hipError_t gd_kernels_init_device(void)
     set(reinterpret_cast<const void *>(&k_fill<false, true, true>), 128 * 1024);
     set(reinterpret_cast<const void *>(&k_fill<true, true, false>), 128 * 1024);
     set(reinterpret_cast<const void *>(&k_fill<true, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, false, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<false, true, true, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, false, true>), 128 * 1024);
+    set(reinterpret_cast<const void *>(&k_fill<true, true, true, true>), 128 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<0>), 64 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<1>), 64 * 1024);
     set(reinterpret_cast<const void *>(&k_softwell<2>), 64 * 1024);

@@ -35,6 +35,7 @@
 #define GD_TILED_MAX_W (GD_TILED_MAX_NEAR + GD_TILED_MAX_FAR)
 #define GD_REC_ID_MASK 0x03ffffffu         // bead id field of rec_mo.y; all ones = no bead
 #define GD_DMAX_STRIDE 32u                  // words between the replicas' displacement maxima: one 128-byte line each
+#define GD_REPAIR_QUEUE 4096u              // k_step waves one build can repair (the blocks of the repair launch); beyond: flagged, rolled back
 #define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 
 enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
@@ -273,21 +274,25 @@ struct BuildParams {
     int w_valid;                        // pos_in.w already holds the packed (a,b) (written by an earlier build, kept by every step)
     unsigned cpb, tile_cap;
     unsigned *flags;
-    unsigned long long *lcount;         // [R] directed list entries
+    unsigned long long *lcount;         // [2 R] directed list entries per replica, then (tiled lists) their near entries in fours
     float4 *rec_x0; uint2 *rec_mo;      // per-thread records of the tiled path (see StepParams)
     unsigned char *len_prev;            // [R*N] by bead id: list batches at the previous build (the balancing sort key)
     // Ragged rows of the tiled lists.  The rows of one k_step wave (64 threads, ordered by list length: near-uniform lists) are as
     // wide as the wave's longest list needs; a build takes them from one pool (nbr16) with a bump cursor, one atomic per block.
     // The width has to be known before the first entry is written: it is PREDICTED from what each bead needed at the build before
     // (need_prev, + an eighth and a chunk to spare per class; without history: p.W entries).  A list that outgrows its wave's rows
-    // is repaired inside k_fill: rows keep counting past their width, so the block's last wave to finish knows the exact need,
-    // takes fresh rows of that width from the pool and lists the 64 beads of that wave again (no rollback, no second launch).
-    // Only a FULL POOL is the host's business: GD_FLAG_OVERFLOW bit 4, the cursor keeps counting -- its final value is the need.
+    // is repaired: rows keep counting past their width, so the exact need is known when the block ends -- its last wave queues the
+    // k_step waves concerned, and the repair kernel behind k_fill (k_fill<..., REPAIR>: one wave per queue item) takes fresh rows of
+    // that width from the pool and lists the 64 beads of the wave again.  No rollback; the queue is empty in almost every build.
+    // Only a FULL POOL (or queue) is the host's business: GD_FLAG_OVERFLOW bit 4; the cursor keeps counting -- its final value is the need.
     uint2 *wtab;                        // [R * Np / 64] (first KiB, chunks per lane) per k_step wave
     unsigned short *need_prev;          // [R*N] by bead id: near chunks (10 bits) | far chunks << 10 (6 bits) the last build counted
     unsigned *pool;                     // [0] cursor (KiB taken so far; its final value is the pool's use, or the need when it was full; k_scan
                                         // starts it over), [1] the largest final value of the builds before this one, [2] k_step waves
-                                        // repaired -- [1] and [2] since the host last cleared them (with the flags)
+                                        // repaired -- [1] and [2] since the host last cleared them (with the flags) --, [3] items in the
+                                        // repair queue of this build (k_scan starts it over)
+    uint2 *rqueue;                      // repair queue: x = (replica * nblk + block) << 3 | k_step wave of the block, y = chunks per lane needed
+    unsigned rq_cap;                    // items the queue holds (= blocks of the repair launch)
     unsigned pool_cap;                  // KiB of the pool
     int predict;                        // 1: need_prev describes these beads (the build before ran at this radius and class mode)
     unsigned long long *dbg;            // section stamps of timing-only builds (the force-output buffer)

@@ -63,7 +63,7 @@ typedef struct {
  * of them changes.  A caller compiled against another version would have the library read or write past its structs, so
  * handle creation carries the caller's version and fails with GD_EINVAL on a mismatch: gd_create() is a macro over
  * gd_create_abi().  Bindings that do not go through this header (ctypes) pass their own constant. */
-#define GD_ABI_VERSION 4
+#define GD_ABI_VERSION 5
 int gd_abi_version(void);
 int gd_create_abi(int abi_version, const gd_desc *desc, gd_system **out);
 #define gd_create(desc, out) gd_create_abi(GD_ABI_VERSION, (desc), (out))
@@ -229,6 +229,12 @@ typedef struct {
     uint32_t compensated;        /* 1: the last gd_run stepped with the compensated position update (gd_run, below) */
     uint32_t largest_tile;       /* LDS-tiled lists: beads in the largest tile of the last build, over all replicas (what decides the
                                     tile class, and with it the list width the handle selects) */
+    uint32_t row_repairs;        /* LDS-tiled lists: k_step waves whose rows the builds of the last chunk wrote twice (a list outgrew the
+                                    width predicted for its wave: repaired on the device, no rollback) */
+    uint64_t near_entries;       /* LDS-tiled lists: entries of this replica's NEAR class, in the fours k_step walks them in (every step
+                                    walks these; the rest of list_entries only once displacements make it matter) */
+    uint64_t list_bytes;         /* memory the lists of the whole handle occupy: tiled lists the rows taken from the pool by the last
+                                    build (ragged rows: every wave as wide as its longest list), generic lists uniform rows */
 } gd_context;
 
 int gd_get_context(gd_system *sys, uint32_t replica, gd_context *out);
