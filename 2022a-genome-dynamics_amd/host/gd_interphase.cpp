@@ -120,9 +120,9 @@ public:
         gd_context c;
         chk(gd_get_context(_sys, 0, &c));
         char line[256];
-        std::snprintf(line, sizeof line, "%s: list path %u, %.1f entries per bead, radius %.4f, interval %u, %llu builds, %llu rollbacks",
+        std::snprintf(line, sizeof line, "%s: list path %u, %.1f entries per bead, radius %.4f, interval %u, %llu builds, %llu rollbacks, lists %.2f GB",
                       phase, c.list_path, (double)c.list_entries / (double)_n, c.list_radius, c.rebuild_interval,
-                      (unsigned long long)c.rebuilds, (unsigned long long)c.rollbacks);
+                      (unsigned long long)c.rebuilds, (unsigned long long)c.rollbacks, (double)c.list_bytes / 1e9);
         g_timing.note(line);
     }
 
