@@ -135,6 +135,7 @@ struct gd_system {
     uint32_t last_need_w = 0;      // longest list (entries, padded) the last build reported
     uint32_t ncell_seen = 0;       // largest cell grid of the last build that reported one (sizes k_scan's launch)
     uint32_t dense_budget = 0;     // dense_guard: longest list (entries) the memory budget admits
+    bool dense_by_tile = false;    // the width was narrowed because the largest tile did not fit the LDS (handle_overflow): returns by tile size
     bool all_near = false;         // single-class lists (near radius = list radius): a build met a far class beyond the tiled record's
                                    // 504 entries; two classes again once the longest list is below that
     uint32_t K = 4, adapt = 1;
@@ -1004,7 +1005,30 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
         // generic path's global gathers -- S-1kb-250k x 16: 471 us per step generic, 239 us tiled at two blocks per CU)
         const unsigned cap_max = 8192u;
         if (cap <= cap_max) { s->tile_cap = cap; s->tile_hold = 4; }
-        else { s->tiled_ok = false; s->tiled_off = 1; }     // too dense for one tile: generic path (retried later with back-off)
+        else {
+            // Too dense for one tile at this list width (the spline-refined start of the pipeline: a globule whose core holds thousands
+            // of beads per list sphere).  A tile is the block's own cells plus their neighbour cells: it shrinks about with the square of
+            // the list radius -- so the width is narrowed until the largest tile fits the LDS (at least a skin of 0.15 x cutoff; builds
+            // get more frequent, but the state stays on the tiled path: global-gather lists cost 2-2.4 x per step there and uniform rows
+            // of the longest list), and class_skin returns to the width it left once the largest tile, scaled back, fits again.  Only
+            // when that is not enough -- or the caller pinned the width -- the generic path takes over (retried later with back-off).
+            const double cut = pair_cutoff(s);
+            bool narrowed = false;
+            if (!s->skin_fixed && cut > 0 && s->rv > 0 && need_t < (1u << 20)) {
+                const double sc = s->rv / cut - s->skin;
+                const double ratio = std::min(0.97, std::max(0.5, std::sqrt(0.85 * (double)cap_max / (double)need_t)));
+                const double skin_new = std::max(0.15, s->rv * ratio / cut - sc);
+                if (skin_new < s->skin - 1e-9) {
+                    if (!(s->skin_dense_from > 0)) s->skin_dense_from = s->skin;
+                    s->skin = skin_new; s->skin_next = 0; s->a2_ema = 0; s->dense_by_tile = true;
+                    if (s->adapt) s->K = std::max(1u, std::min(s->K, 4u));
+                    s->tile_cap = cap_max; s->tile_hold = 4;
+                    narrowed = true;
+                    if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state (largest tile %u): skin %.3f\n", need_t, skin_new);
+                }
+            }
+            if (!narrowed) { s->tiled_ok = false; s->tiled_off = 1; }
+        }
     }
     if (over) {
         // Tiled lists (ragged rows): the pool was full -- its cursor counted on, pool_used is the need and the next build sizes the pool
@@ -1254,6 +1278,21 @@ static void class_skin(gd_system *s, const gd_run_desc *run)
         // again; the timing-based selection, when enabled, starts from there
         const unsigned need_w = s->last_need_w;
         const double cut = pair_cutoff(s), sc0 = s->rv / cut - s->skin, ratio = (sc0 + s->skin_dense_from) / (sc0 + s->skin);
+        // (narrowed for the memory of the rows: back when the longest list, scaled with the cube of the radius, fits the budget again;
+        // narrowed for the LDS tile: back -- in steps of at most a quarter of the width, the densest tile decides -- when the largest
+        // tile, scaled with the square of the radius, fits 0.7 of the LDS)
+        if (s->dense_by_tile) {
+            if (s->list_tiled && s->last_need_t > 0 && !(s->skin_next > 0)) {
+                const double target = std::min(s->skin_dense_from, s->skin * 1.25 + 0.02);
+                const double rt = (sc0 + target) / (sc0 + s->skin);
+                if ((double)s->last_need_t * rt * rt <= 0.7 * 8192.0) {
+                    s->skin_next = target;
+                    if (target >= s->skin_dense_from - 1e-9) { s->skin_dense_from = 0; s->dense_by_tile = false; }
+                    if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state eases (largest tile %u): skin %.3f at the next build\n", s->last_need_t, s->skin_next);
+                }
+            }
+            return;
+        }
         if (need_w > 0 && (double)need_w * ratio * ratio * ratio <= 0.8 * (double)s->dense_budget && !(s->skin_next > 0)) {
             s->skin_next = s->skin_dense_from; s->skin_dense_from = 0;
             { const bool on = s->tuner.enabled; s->tuner = gd_system::SkinTuner{}; s->tuner.enabled = on; }      // (a fresh selection from the default width)

@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
         constexpr int GD_TILE_PLANES = 10;
         const int z0 = r0 / ny, z1 = r1 / ny;
         const bool ok = nx >= 3 && ny >= 3 && nz >= 3 && z1 - z0 + 1 <= GD_TILE_PLANES;
-        unsigned total = 0; int nm = 0; bool truncated = !ok;
+        unsigned total = 0, full = 0; int nm = 0; bool truncated = !ok;
         for (int k = 0; k < GD_TILE_RANGES; k++) { td.start[k] = 0; td.len[k] = 0; td.base[k] = 0; td.kstart[k] = 0xffffffffu; td.kbase[k] = 0; }
         if (!ok) {      // grid too small (aliasing neighbours) or the block spans too many planes: generic path
             if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
@@ -1427,16 +1427,19 @@ __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
             i++;
             while (i < nrun && ra[i] <= e + 1) { e = max(e, rb[i]); i++; }      // overlapping and adjacent runs merge
             const unsigned st = cs[q * nx], len = cs[(e + 1) * nx] - st;
+            full += len;
+            if (truncated) continue;      // (the tile does not fit: the rest is only counted -- the host sizes the next attempt from the whole)
             if (nm >= GD_TILE_RANGES || total + len > p.tile_cap) {
                 if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
                 // too many ranges cannot be cured by a larger tile: report a need beyond every capacity
-                if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], nm >= GD_TILE_RANGES ? 1u << 20 : total + len);
+                if (!taint && nm >= GD_TILE_RANGES) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], 1u << 20);
                 truncated = true;
-                break;
+                continue;
             }
             td.start[nm] = st; td.len[nm] = len; td.base[nm] = total;
             total += len; nm++;
         }
+        if (truncated && !taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], full);
         td.nranges = truncated ? 0u : (unsigned)nm;
         td.total = total;
         td.own_base = 0;
@@ -1478,15 +1481,15 @@ __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
     for (int m = 0; m < NR; m++) { st[m] = cs[m < nm ? mlo[m] : 0]; en[m] = cs[m < nm ? mhi[m] + 1 : 0]; }
 #pragma unroll
     for (int k = 0; k < NR; k++) ks[k] = cs[val[k] ? lo[k] : 0];
-    unsigned total = 0;
+    unsigned total = 0, full = 0;
     bool truncated = false;
 #pragma unroll
     for (int m = 0; m < NR; m++) {
         const unsigned s0 = m < nm ? st[m] : 0u;
         unsigned len = m < nm ? en[m] - st[m] : 0u;
-        if (total + len > p.tile_cap) {   // does not fit the LDS budget: flag, host rolls back and re-plans
+        full += len;
+        if (total + len > p.tile_cap) {   // does not fit the LDS budget: flag, host rolls back and re-plans (from the WHOLE tile's size, below)
             if (!taint) p.flags[r * GD_NFLAGS + GD_FLAG_TILE_OVERFLOW] = 1u;
-            if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total + len);
             len = 0; truncated = true;
         }
         td.start[m] = s0; td.len[m] = len; td.base[m] = total;
@@ -1510,7 +1513,7 @@ __global__ __launch_bounds__(64) void k_tiles(const BuildParams p)
     td.own_base = own_base;
     td.pad_[0] = 0; td.pad_[1] = 0;
 
-    if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], total);
+    if (!taint) atomicMax(&p.flags[r * GD_NFLAGS + GD_FLAG_NEED_TILE], truncated ? full : total);
     p.tiles[t] = td;
 }
 

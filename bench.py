@@ -408,10 +408,9 @@ def main():
         alg_bytes = 204.0 * N * R
         alg_gbs = alg_bytes / (kms * 1e-3) / 1e9
         meas_gbs = traffic / (kms * 1e-3) / 1e9 if traffic else None
-        # list entries a bead walks per step, averaged over an interval: the whole near class + the far class while it is walked.
-        # The handle reports the entries of the list (both classes); the near share comes with the PMC pass's workload (near_fraction
-        # of the profile, 0.476 on this state) -- priced at the full list here, an upper bound of the design's need
-        walked = L_launch / (N * R)
+        # list entries a bead HAS to walk per step: its near class (counted by the build in the fours k_step walks, gd_context.near_entries
+        # of replica 0); the far class joins only in the last steps of an interval -- a lower bound, as a minimum should be
+        walked = ctx.near_entries / N if ctx.near_entries else L_launch / (N * R)
         K_live = max(int(ctx.rebuild_interval), 1)
         whole_bytes = (traffic + tr["build_bytes"] / K_live) if (tr and tr.get("build_bytes")) else None
         whole_frac = whole_bytes / (tm.total_ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS if whole_bytes else None
@@ -435,15 +434,14 @@ def main():
             # whole_step_counter_frac: the same counters over the WHOLE step -- k_step's bytes + the list build's bytes (every kernel of
             # the build chain, same PMC passes) / the live rebuild interval, over the device time per step (steps + builds).
             # design_min_bytes_per_launch: what this design has to move per k_step launch -- per bead-step 16 B position read + 24 B of
-            # per-thread records + 16 B adjacency chunk + 2 B per list entry walked (the near class every step, the far class in the
-            # last steps of an interval: the live mean, list_entries_walked_per_bead_step) + 16 B position store: counter traffic well
-            # above it would be wasted re-reads.
+            # per-thread records + 16 B adjacency chunk + 2 B per NEAR list entry (near_entries_per_bead; the far class joins in the
+            # last steps of an interval only) + 16 B position store: counter traffic well above it would be wasted re-reads.
             "roofline": {"bound": "hbm", "kernel": "k_step", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "achieved": meas_gbs if meas_gbs is not None else alg_gbs,
                          "frac": (meas_gbs if meas_gbs is not None else alg_gbs) / HBM_PEAK_GBS,
                          "frac_kind": "pmc_traffic_over_live_kernel_time" if meas_gbs is not None else "survey_204B_per_bead_step_over_live_kernel_time",
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "design_min_bytes_per_launch": (72.0 + 2.0 * walked) * N * R, "list_entries_walked_per_bead_step": walked,
+                         "design_min_bytes_per_launch": (72.0 + 2.0 * walked) * N * R, "near_entries_per_bead": walked,
                          "whole_step_counter_frac": whole_frac, "whole_step_counter_bytes_per_step": whole_bytes,
                          "avg_launch_ms": kms,
                          "rebuild_ms_per_step": tm.rebuild_ms / launches, "device_total_ms_per_step": tm.total_ms / launches},

@@ -1296,3 +1296,62 @@ def test_two_handles_on_two_host_threads_race_their_first_launches(hip, oracle):
         assert np.abs(F - Fo).max() <= FORCE_RTOL * np.abs(Fo).max()
         assert np.abs(x - so.positions()).max() <= 2 * POS_ATOL_20STEP
         so.close()
+
+
+def test_ragged_rows_globule_and_gas_in_one_handle(hip, oracle):
+    """Ragged rows (round 5): a dense globule (lists of several hundred entries) and a dilute gas (a handful) in ONE handle -- the
+    rows of a k_step wave are as wide as that wave's longest list, not the handle's.  Forces and the pair set of the resident
+    lists equal the oracle's on the same positions (two replicas, different globules); the lists take a fraction of what uniform
+    rows of the longest list would; a short run (the globule swells, its beads' lists change by whole chunks between builds:
+    predicted widths + on-device repair, no rollback for a row) still matches the oracle's trajectory."""
+    rng = np.random.default_rng(23)
+    n_glob, n_gas, R = 3000, 9000, 2
+    n = n_glob + n_gas
+    def cloud(seed):
+        g0 = np.random.default_rng(seed)
+        v = g0.normal(size=(n_glob, 3))
+        glob = 1.0 * v / np.linalg.norm(v, axis=1)[:, None] * g0.random((n_glob, 1)) ** (1 / 3)       # ~700 beads per unit volume
+        gas = (g0.random((n_gas, 3)) - 0.5) * 9.0 + np.array([7.0, 0.0, 0.0])                          # ~12 per unit volume, elsewhere
+        return np.concatenate([glob, gas])
+    x = np.stack([cloud(101), cloud(202)]).astype(np.float32).astype(np.float64)
+    def make(lib, r_count):
+        s = g.System(lib, n, r_count)
+        s.set_bead_params(a=(np.arange(n) % 2).astype(float), b=((np.arange(n) + 1) % 2).astype(float), mobility=np.ones(n))
+        s.set_pair_softcore(2.0, 0.3, 2.0, 0.24)
+        return s
+    sh = make(hip, R)
+    sh.set_tuning(kernel_path=2)
+    sh.set_positions(x)
+    Fh = sh.forces()
+    c = sh.context()
+    assert c.list_path == 2
+    so = make(oracle, 1)
+    for r in range(R):
+        so.set_positions(x[r])
+        Fo = so.forces()
+        assert np.abs(Fh[r] - Fo).max() <= FORCE_RTOL * np.abs(Fo).max()
+        ph = {tuple(p) for p in sh.search_pairs(0.3, replica=r)}
+        po = {tuple(p) for p in so.search_pairs(0.3)}
+        for i, j in ph ^ po:
+            assert abs(np.linalg.norm(x[r][i] - x[r][j]) - 0.3) < 1e-6
+        assert len(po) > 50000
+    # the globule's beads hold hundreds of entries, the gas a few: mean far below the longest, and the rows follow the mean
+    lens = np.zeros(n)
+    for i, j in po:
+        lens[i] += 1; lens[j] += 1
+    assert lens[:n_glob].mean() > 60 and lens[n_glob:].mean() < 3
+    # (contact pairs are within 0.3, list entries within the list radius 0.525: ~5 x as many; uniform rows hold the longest list for every bead)
+    uniform_bytes = 2.0 * R * ((n + 511) // 512 * 512) * 5.0 * lens.max()
+    assert 0 < c.list_bytes < 0.5 * uniform_bytes, (c.list_bytes, uniform_bytes, lens.max())
+    # a short run from here: the globule swells (lists shrink and shift between the classes), builds every 2 steps
+    sh.set_tuning(kernel_path=2, rebuild_interval=2, adapt_interval=0)
+    sh.begin_phase()
+    rb0 = sh.context().rollbacks
+    sh.run(12, 2e-6, 1.0, seed=SEED, replica_seeds=[5, 6])
+    c1 = sh.context()
+    assert c1.list_path == 2 and c1.rollbacks == rb0, (c1.rollbacks, rb0)
+    x1 = sh.positions()
+    for r in range(R):
+        so.set_positions(x[r]); so.begin_phase()
+        so.run(12, 2e-6, 1.0, seed=[5, 6][r])
+        assert np.abs(x1[r] - so.positions()[0]).max() <= POS_ATOL_20STEP

@@ -22,6 +22,14 @@ for line in open(f"{d}/{tag}{suffix}_bench_pmc_summary.txt"):
 avg_us = None
 for line in open(f"{d}/{tag}{suffix}_bench_kernel_stats.txt"):
     if kern in line: avg_us = float(re.search(r"avg_us\s+([\d.]+)", line).group(1))
+# the list build: every kernel of its chain, same passes (bytes per build = sum over the kernels of their mean per dispatch)
+build, cur = {}, None
+for line in open(f"{d}/{tag}{suffix}_bench_pmc_summary.txt"):
+    if not line.startswith(" "): cur = line.strip()
+    elif cur and re.match(r"(void )?k_(bin|scan|members|scatter|tiles|fill|bbox|gridp)\b", cur):
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches\s+(\d+)\s+mean/dispatch\s+([\d.]+)", line)
+        if m: build.setdefault(cur.replace("void ", "").split("(")[0], {})[m.group(1)] = float(m.group(3))
+build_bytes = sum((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024 for k, v in build.items() if "bbox" not in k and "gridp" not in k)
 fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
 b = (2 * fetch + write) * 1024 * per_step
 if avg_us is not None: avg_us *= per_step
@@ -35,5 +43,7 @@ out = {"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate pa
                   "hbm_gbs": b / (avg_us * 1e-6) / 1e9, "valu_insts_per_wave": vals.get("SQ_INSTS_VALU", (0, 0))[0] / max(vals.get("SQ_WAVES", (1, 0))[0], 1),
                   "wait_fraction_of_wave_cycles": vals.get("SQ_WAIT_ANY", (0, 0))[0] / max(vals.get("SQ_WAVE_CYCLES", (1, 0))[0], 1),
                   "lds_bank_conflict_fraction": vals.get("SQ_LDS_BANK_CONFLICT", (0, 0))[0] / max(vals.get("SQ_LDS_IDX_ACTIVE", (1, 0))[0], 1)}}
+out["build"] = {"corrected_bytes_per_build": build_bytes, "kernels": {k: (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024 for k, v in build.items()},
+                "_comment": "2 x FETCH_SIZE + WRITE_SIZE of every kernel of the list build chain (warm builds: k_bbox / k_gridp not counted), per build"}
 json.dump(out, open(f"profiles/{tag}_traffic{suffix}.json", "w"), indent=1)
 print(json.dumps(out["k_step"]))
