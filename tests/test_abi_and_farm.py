@@ -257,3 +257,32 @@ def test_bench_two_rccl_ranks_on_one_device_or_the_refusal_recorded(hip):
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dist_backend"] == "nccl"
     assert line["cpu_shares_disjoint"] is True and len(line["bead_steps_per_s_per_rank"]) == 2
     assert line["config"]["global_replicas"] == 16 and line["value"] > 0
+
+
+def test_every_entry_point_makes_its_device_current_before_its_first_hip_call():
+    """include/gdyn.h: independent handles may live on different threads AND devices.  Audit of csrc/gdyn_capi.hip: every extern "C"
+    entry point that reaches the HIP runtime sets the handle's device first -- hipSetDevice itself or one of the helpers that start
+    with it (prepare, fetch_xyz, apply_pending, finalize_topology)."""
+    import re
+    src = open(os.path.join(ROOT, PKG_DIR, "csrc", "gdyn_capi.hip")).read()
+    src = re.sub(r"//[^\n]*", "", src)
+    starts = [m.start() for m in re.finditer(r'^extern "C" ', src, re.M)] + [len(src)]
+    helpers = r"hipSetDevice|prepare\(s\)|fetch_xyz\(s|apply_pending\(s\)|finalize_topology\(s\)"
+    for h in ("prepare", "fetch_xyz", "apply_pending", "finalize_topology"):      # the helpers do start with it (apply_pending: once something is pending)
+        body = src[src.index("static int " + h + "("):]
+        body = body[:body.index("\n}\n")]
+        first_hip = re.search(r"\bhip[A-Z]\w+\s*\(|gd_launch_", body)
+        assert first_hip and (first_hip.group(0).startswith("hipSetDevice") or re.search(helpers, body[:first_hip.start()])), h
+    checked = 0
+    for a, b in zip(starts, starts[1:]):
+        fn = src[a:b]
+        first_line = fn.split("\n", 1)[0]
+        fn = first_line if first_line.count("{") == first_line.count("}") and "{" in first_line else (fn[:fn.index("\n}\n")] if "\n}\n" in fn else fn)
+        name = re.search(r"(gd_\w+)\s*\(", fn).group(1)
+        uses = re.search(r"\bhip(?!GetDeviceCount|GetErrorString|Success|Error_t)[A-Z]\w+\s*\(|gd_launch_|build_now\(|ensure_fresh_list\(|search_device\(|upload_ctx\(|download_ctx\(|\.resize\(", fn)
+        if not uses:
+            continue
+        sets = re.search(helpers, fn)
+        assert sets and sets.start() <= uses.start(), name
+        checked += 1
+    assert checked >= 12
