@@ -165,6 +165,7 @@ struct gd_system {
     float need_rv = 0; bool need_all_near = false;      // list radius / class mode need_prev was counted at
     uint32_t pool_used = 0;        // KiB the last build took (its cursor's final value: the need, when the pool was full)
     uint32_t repairs = 0;          // k_step waves the last build read back had to repair (diagnostics)
+    uint32_t repair_wide = 0;      // > 0: accepted chunks still to run with a repair block for EVERY wave (a build queued more than GD_REPAIR_GRID)
     DevBuf<float> bbox;
     DevBuf<float2> ab; DevBuf<float> mobs; DevBuf<float4> bendE; DevBuf<int4> chain;
     float mob_uniform = -1.f;
@@ -274,7 +275,7 @@ extern "C" int gd_create_abi(int abi_version, const gd_desc *d, gd_system **out)
          s->lcount_d.resize(2 * (size_t)s->R) == hipSuccess && s->dmax.resize((size_t)s->R * GD_DMAX_STRIDE) == hipSuccess && s->fout.resize(RN) == hipSuccess && s->snap.resize(RN) == hipSuccess &&
          s->tiles.resize((size_t)s->R * s->nblk) == hipSuccess &&
          s->rec_x0.resize(RNp) == hipSuccess && s->rec_mo.resize(RNp) == hipSuccess && s->len_prev.resize((size_t)s->R * s->N) == hipSuccess &&
-         s->wtab.resize(RNp / 64) == hipSuccess && s->need_prev.resize((size_t)s->R * s->N) == hipSuccess && s->pool.resize(4) == hipSuccess && s->rqueue.resize(GD_REPAIR_QUEUE) == hipSuccess &&
+         s->wtab.resize(RNp / 64) == hipSuccess && s->need_prev.resize((size_t)s->R * s->N) == hipSuccess && s->pool.resize(4) == hipSuccess && s->rqueue.resize(RNp / 64) == hipSuccess &&
          s->lo.resize(RN) == hipSuccess;
     s->lo_valid = ok;      // (positions and residuals all zero)
     if (!ok) { delete s; return fail(GD_ENOMEM, "gd_create: device allocation failed (%zu slots)", RNp); }
@@ -867,7 +868,7 @@ static int enqueue_build(gd_system *s, float rv, bool with_list, bool allow_tile
     b.packed_ab = s->packed_ab ? 1 : 0; b.cpb = s->cpb; b.tile_cap = s->tile_cap;
     b.w_valid = (s->packed_ab && s->w_packed) ? 1 : 0;
     b.flags = s->flags.p; b.lcount = s->lcount_d.p; b.dbg = (unsigned long long *)s->fout.p;
-    b.wtab = s->wtab.p; b.need_prev = s->need_prev.p; b.pool = s->pool.p; b.rqueue = s->rqueue.p; b.rq_cap = GD_REPAIR_QUEUE;
+    b.wtab = s->wtab.p; b.need_prev = s->need_prev.p; b.pool = s->pool.p; b.rqueue = s->rqueue.p; b.rq_cap = (unsigned)s->rqueue.n; b.rq_grid = s->repair_wide > 0 ? b.rq_cap : std::min(GD_REPAIR_GRID, b.rq_cap);
     if (tiled) {
         // Ragged rows (BuildParams): every k_step wave's rows are as wide as its longest list, predicted from what each bead needed at
         // the build before (no history -- first build, positions from the caller, another list radius or class mode: W entries per
@@ -1032,9 +1033,15 @@ static bool handle_overflow(gd_system *s, const std::vector<unsigned> &f)
     }
     if (over) {
         // Tiled lists (ragged rows): the pool was full -- its cursor counted on, pool_used is the need and the next build sizes the pool
-        // from it (a list that outgrows its predicted row is repaired inside k_fill and never gets here).  Generic lists (uniform
+        // from it -- or a build queued more waves for repair than the repair launch has blocks: the next chunks launch one per wave
+        // (a list that outgrows its predicted row is repaired on the device and never gets here).  Generic lists (uniform
         // rows): the overflowing build has counted the longest list exactly (a row keeps counting past its width): the next build
         // gets that width with 6 % to spare.
+        {
+            unsigned bits = 0;
+            for (uint32_t r = 0; r < s->R; r++) bits |= f[r * GD_NFLAGS + GD_FLAG_OVERFLOW];
+            if (s->list_tiled && (bits & 4u) && (size_t)s->pool_used <= s->nbr16.n / 512) s->repair_wide = 16;      // (bit 4 with room in the pool: the repair queue)
+        }
         if (!s->list_tiled) {
             unsigned w = need_w + need_w / 16 + 8;
             s->W = std::max(w, s->W + 8);
@@ -1559,6 +1566,7 @@ extern "C" int gd_run(gd_system *s, const gd_run_desc *run)
         if (with_list) tune_skin(s, ms, chunk, full_interval, false);
         if (with_list && full_interval) class_skin(s, run);
         done += chunk; chunk_retries = 0;
+        if (s->repair_wide > 0) s->repair_wide--;
     }
     // The last chunk was accepted: every bead is within the margin the list in use was built for, at the cutoff of the last step.
     // That is still the cutoff an observation sees when the scales did not move behind that step (callback deferred, or no scale

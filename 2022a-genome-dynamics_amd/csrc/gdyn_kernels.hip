@@ -1606,7 +1606,7 @@ __global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERI
     __shared__ unsigned s_wn[GD_BLOCK / 64], s_woff[GD_BLOCK / 64], s_wneed[GD_BLOCK / 64];      // (s_wneed: what the lists turned out to need)
     unsigned r, blk, rep_w = 0, rep_need = 0;
     if (REPAIR) {
-        if (blockIdx.x >= min(p.pool[3], p.rq_cap)) return;      // (queue items; one block = one wave each)
+        if (blockIdx.x >= min(p.pool[3], p.rq_cap)) return;      // (queue items; one block = one wave each; the launch has rq_grid blocks)
         const uint2 item = p.rqueue[blockIdx.x];
         r = (item.x >> 3) / p.nblk; blk = (item.x >> 3) % p.nblk; rep_w = item.x & 7u; rep_need = item.y;
     } else if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
@@ -2141,8 +2141,10 @@ __global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERI
                     const unsigned need = atomicMax(&s_wneed[w], 0u), have = s_wn[w];
                     if (have != 0u && need > have) {
                         const unsigned at = atomicAdd(&p.pool[3], 1u);
-                        if (at < p.rq_cap) p.rqueue[at] = make_uint2(((r * p.nblk + blk) << 3) | w, need);
-                        else if (!p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);      // (more than the queue holds: the chunk is rolled back, the next build predicts from these needs)
+                        if (at < p.rq_cap) p.rqueue[at] = make_uint2(((r * p.nblk + blk) << 3) | w, need);      // (the queue holds every wave of the handle)
+                        // more waves than the repair launch has blocks (a state that changes faster than a build predicts): flagged, the
+                        // chunk is rolled back and the host launches the repair kernel with a block for every wave until that has passed
+                        if (at >= p.rq_grid && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);
                         atomicAdd(&p.pool[2], 1u);      // (repaired waves: diagnostics)
                     }
                 }
@@ -2176,7 +2178,7 @@ void gd_launch_build(const BuildParams &p, hipStream_t st)
     if (p.tiled) {
         const size_t lds = (size_t)(p.tile_cap + 4) * sizeof(float4);   // +4: read slack
         // (behind it the repair kernel: one wave per queued k_step wave; its blocks leave at once while the queue is empty)
-        const dim3 gridr(p.rq_cap), blockr(64);
+        const dim3 gridr(p.rq_grid), blockr(64);
         if (p.periodic) {
             if (p.tile_cap < 4096u) { hipLaunchKernelGGL((k_fill<true, true, true>), gridx, block, lds, st, p); hipLaunchKernelGGL((k_fill<true, true, true, true>), gridr, blockr, lds, st, p); }
             else { hipLaunchKernelGGL((k_fill<true, true, false>), gridx, block, lds, st, p); hipLaunchKernelGGL((k_fill<true, true, false, true>), gridr, blockr, lds, st, p); }

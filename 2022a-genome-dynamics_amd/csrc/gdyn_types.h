@@ -35,7 +35,8 @@
 #define GD_TILED_MAX_W (GD_TILED_MAX_NEAR + GD_TILED_MAX_FAR)
 #define GD_REC_ID_MASK 0x03ffffffu         // bead id field of rec_mo.y; all ones = no bead
 #define GD_DMAX_STRIDE 32u                  // words between the replicas' displacement maxima: one 128-byte line each
-#define GD_REPAIR_QUEUE 4096u              // k_step waves one build can repair (the blocks of the repair launch); beyond: flagged, rolled back
+#define GD_REPAIR_GRID 4096u               // blocks of the repair launch behind every k_fill (one k_step wave each; they leave at once while the
+                                           // queue is empty); a build that queues more is flagged, and the host launches one block per wave
 #define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 
 enum { GD_MODE_STEP = 0, GD_MODE_FORCE = 1, GD_MODE_ENERGY = 2 };
@@ -292,7 +293,8 @@ struct BuildParams {
                                         // repaired -- [1] and [2] since the host last cleared them (with the flags) --, [3] items in the
                                         // repair queue of this build (k_scan starts it over)
     uint2 *rqueue;                      // repair queue: x = (replica * nblk + block) << 3 | k_step wave of the block, y = chunks per lane needed
-    unsigned rq_cap;                    // items the queue holds (= blocks of the repair launch)
+    unsigned rq_cap;                    // items the queue holds: every k_step wave of the handle
+    unsigned rq_grid;                   // blocks of the repair launch (GD_REPAIR_GRID; rq_cap while a fast-changing state needs more)
     unsigned pool_cap;                  // KiB of the pool
     int predict;                        // 1: need_prev describes these beads (the build before ran at this radius and class mode)
     unsigned long long *dbg;            // section stamps of timing-only builds (the force-output buffer)

@@ -341,11 +341,12 @@ typedef struct {
                                    i.e. an absolute width that a scaled-down cutoff does not shrink.  A value > 0 pins the width.
                                    0 keeps the library's own choice: 0.75, widened to 0.9 while the largest LDS tile of the wider
                                    list fits the three-block class (a rule on the state: tile sizes are cell counts; see
-                                   DESIGN.md section 4), narrowed while a dense state's longest list would not fit the
-                                   memory budget */
+                                   DESIGN.md section 4), narrowed while a dense state's largest tile would not fit the LDS (or its
+                                   rows a sixteenth of the device memory); < 0 returns a pinned handle to the library's choice */
     uint32_t rebuild_interval;  /* initial steps between list builds; 0 = auto */
     uint32_t adapt_interval;    /* 1 = adapt interval from measured displacements */
-    uint32_t list_width;        /* initial max neighbours per bead (grows on overflow) */
+    uint32_t list_width;        /* neighbours per bead the first list build allows for: the uniform row width of generic lists (grows on
+                                   overflow), the guess the ragged rows of tiled lists start from before a build has counted the needs */
     uint32_t kernel_path;       /* 0 auto (LDS-tiled where the tiles fit, else generic), 1 generic (global-gather lists),
                                    2 LDS-tiled preferred: needs fp16-exact a/b factors, tiles that fit the LDS and rows of at most
                                    1016 near + 504 far entries; where that does not hold the build falls back to generic lists (a dense

@@ -1,7 +1,9 @@
 #!/bin/bash
-root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/dbg; mkdir -p $out
+# debug: the 128-file pipeline with a developer-library build of gd_interphase (host prints of the library on stderr)
+root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/dbg; mkdir -p $out/bin
 cd $root
-GDYN_DEBUG=2 GDYN_TEST_LIB=libgdyn_dev.so timeout -k 5 120 python3 -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "$1" > $out/dbg.log 2>&1
-echo "rc=$?" >> $out/dbg.log
-grep -v "^\[gdyn\] build" $out/dbg.log | head -60
-grep "^\[gdyn\] build" $out/dbg.log | head -12
+make -s -C 2022a-genome-dynamics_amd/host OUTDIR=$out/bin GDYN_LIB=gdyn_dev $out/bin/gd_interphase > $out/make.log 2>&1 || { tail -5 $out/make.log; exit 1; }
+GDYN_DEBUG=1 GD_INTERPHASE_BIN=$out/bin/gd_interphase PIPE_ERR_FILE=$out/interphase.err timeout -k 10 900 python3 tools/pipeline_scale.py 128 5000 > $out/pipeline_128.json 2> $out/pipeline_128.err
+echo "rc=$?"
+grep "^\[gdyn\]" $out/interphase.err | tail -60 > $out/gdyn_tail.txt; grep -c "^\[gdyn\]" $out/interphase.err; cat $out/gdyn_tail.txt | cut -c1-220
+rm -rf $out/bin

@@ -19,6 +19,8 @@ def run(*cmd):
     t0 = time.perf_counter()
     r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, env=env)
     if r.returncode:
+        if os.environ.get("PIPE_ERR_FILE"):      # (debugging: the whole stderr of the failed program)
+            open(os.environ["PIPE_ERR_FILE"], "w").write(r.stderr)
         sys.exit(f"{cmd[0]} failed:\n{r.stderr[-3000:]}")
     return time.perf_counter() - t0, r
 
@@ -57,7 +59,7 @@ for r in range(R):
     t_prep["refine"] = t_prep.get("refine", 0) + run(sys.executable, os.path.join(HOST, "gd_refine.py"), f)[0]
     files.append(f)
 # (GD_INTERPHASE_WRAP="rocprofv3 --kernel-trace --stats -d <dir> --": the program under the profiler, directly after the "--")
-t_inter, res = run(*os.environ.get("GD_INTERPHASE_WRAP", "").split(), os.path.join(HOST, "gd_interphase"), "--timing",
+t_inter, res = run(*os.environ.get("GD_INTERPHASE_WRAP", "").split(), os.environ.get("GD_INTERPHASE_BIN") or os.path.join(HOST, "gd_interphase"), "--timing",
                    *os.environ.get("GD_INTERPHASE_ARGS", "").split(), *files)
 log = [ln for ln in res.stderr.splitlines() if ln.startswith("[")]
 total_steps = cfg["relaxation_steps"] + steps

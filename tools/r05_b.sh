@@ -3,7 +3,7 @@
 tag=${1:-r05b}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/$tag; mkdir -p $out
 cd $root
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > $out/tests.log 2>&1
+timeout -k 10 900 python3 -m pytest tests -x -q -rs -m gpu > $out/tests.log 2>&1
 rc=$?; echo "tests rc=$rc"; tail -3 $out/tests.log
 [ $rc -ne 0 ] && exit $rc
 cd /tmp; export TMPDIR=/tmp
