@@ -506,6 +506,9 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
 #ifdef GD_REPLAY
         if (RP_MEM) return;
 #endif
+#if GD_ABL == 53
+        if (MODE == GD_MODE_STEP) return;      // (census build: no noise)
+#endif
         if (MODE == GD_MODE_STEP && (TILED ? oid != GD_REC_ID_MASK : valid) && p.kT > 0.f) {
             if (p.noise_mode == NOISE_PHILOX) {
                 const long long step_now = ctx_step0 + (ctx_pending0 ? 1 : 0);
@@ -555,7 +558,18 @@ __global__ __launch_bounds__(GD_BLOCK, (TILED && MODE == GD_MODE_STEP) ? (S16 ? 
         }
     }
 
-    const unsigned mask = (MODE == GD_MODE_STEP) ? 63u : p.term_mask;
+    // (census builds, make abl N=51 ... 54: the stepping kernel without its pair / bond / wall section, or without the noise -- timing and
+    // counter builds only, wrong physics: the section's dynamic instruction count is the product's minus the build's, tools/census_pmc.sh)
+#if GD_ABL == 51
+    constexpr unsigned STEP_TERMS = 63u & ~TERM_PAIR;
+#elif GD_ABL == 52
+    constexpr unsigned STEP_TERMS = 63u & ~(TERM_BOND | TERM_DYNAMIC);
+#elif GD_ABL == 54
+    constexpr unsigned STEP_TERMS = 63u & ~TERM_WALL;
+#else
+    constexpr unsigned STEP_TERMS = 63u;
+#endif
+    const unsigned mask = (MODE == GD_MODE_STEP) ? STEP_TERMS : p.term_mask;
 
     float3 F = make_float3(0.f, 0.f, 0.f);
     float3 react = make_float3(0.f, 0.f, 0.f);
