@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERI
     } else if (!block_map(blockIdx.x, p.nblk, p.cpb, r, blk)) return;
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_acc_cnt = 0ull; s_acc_max = 0u; s_acc_done = 0u; }
-    if (threadIdx.x < GD_BLOCK / 64) { s_wn[threadIdx.x] = 0u; s_woff[threadIdx.x] = 0u; s_wneed[threadIdx.x] = 0u; }
+    if (threadIdx.x < GD_BLOCK / 64) { s_wn[threadIdx.x] = 0u; s_woff[threadIdx.x] = 0xffffffffu; s_wneed[threadIdx.x] = 0u; }
     if (!TILED) __syncthreads();      // (the tiled path has its barriers below)
     const size_t rbase = (size_t)r * p.Np;
     unsigned slot = blk * GD_BLOCK + threadIdx.x;      // (REPAIR: set below, from the record of the k_step thread this lane stands for)
@@ -1757,9 +1757,15 @@ __global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERI
             } else want = max(p.W / 8u, 1u);
         }
         atomicMax(&s_wn[wk], want);
-        __syncthreads();
+        // No barrier for this: every wave counts itself in once its lanes' widths are in (the counter the end of the kernel uses for "last
+        // wave done": it simply starts from eight there), wave 0 alone waits for the eight, allocates, and publishes (s_wn, then s_woff);
+        // the other waves go on into the re-map and pick their rows up where they first need them -- a barrier behind the re-map made
+        // all eight waves start their sweeps in lock step and cost the block the latency of the cursor's atomic.
+        if (lane == 0) { __threadfence_block(); atomicAdd(&s_acc_done, 1u); }
         if (threadIdx.x < GD_BLOCK / 64) {      // eight lanes of wave 0: prefix of the widths, ONE atomic on the pool's cursor per block
-            const unsigned nc = s_wn[threadIdx.x];
+            while (atomicAdd(&s_acc_done, 0u) < GD_BLOCK / 64) __builtin_amdgcn_s_sleep(1);
+            __threadfence_block();
+            const unsigned nc = atomicMax(&s_wn[threadIdx.x], 0u);
             unsigned incl = nc;
             for (int o = 1; o < GD_BLOCK / 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
             const unsigned total = __shfl(incl, GD_BLOCK / 64 - 1, 64);
@@ -1772,9 +1778,10 @@ __global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERI
             if (!fits && threadIdx.x == 0 && !p.flags[r * GD_NFLAGS + GD_FLAG_TAINT]) atomicOr(&p.flags[r * GD_NFLAGS + GD_FLAG_OVERFLOW], 4u);
             const unsigned off = fits ? base + incl - nc : 0u;
             p.wtab[(rbase + (size_t)blk * GD_BLOCK) / 64 + threadIdx.x] = make_uint2(off, fits ? nc : 0u);
-            s_woff[threadIdx.x] = off; s_wn[threadIdx.x] = fits ? nc : 0u;
+            s_wn[threadIdx.x] = fits ? nc : 0u;
+            __threadfence_block();
+            *(volatile unsigned *)&s_woff[threadIdx.x] = off;      // (published: 0xffffffff until here)
         }
-        // (the cursor's answer is needed behind the re-map of the bonded topology below: a barrier there, not here)
     }
     GD_FSTAMP(0);     // staging + barrier
     unsigned cnt = 0, near4 = 0;
@@ -1830,9 +1837,10 @@ __global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERI
         }
     }
     GD_FSTAMP(1);     // bond / chain re-map
-    if (TILED && !REPAIR) {
-        __syncthreads();      // the rows of the block's waves have their place (s_woff, s_wn)
-        row_nc = s_wn[wk]; row_off = s_woff[wk];
+    if (TILED && !REPAIR) {      // the rows of the block's waves have their place once wave 0 has published it (long ago, as a rule)
+        while ((row_off = *(volatile unsigned *)&s_woff[wk]) == 0xffffffffu) __builtin_amdgcn_s_sleep(1);
+        __threadfence_block();
+        row_nc = *(volatile unsigned *)&s_wn[wk];
     }
     if (on) {
         unsigned listlen = 0, nAq = 0, nB = 0;
@@ -2142,7 +2150,7 @@ __global__ __launch_bounds__(REPAIR ? 64 : GD_BLOCK, REPAIR ? 1 : (TILED ? (PERI
     if (lane == 0) {
         atomicAdd(&s_acc_cnt, c64); atomicMax(&s_acc_max, cmax);
         __threadfence_block();       // (this wave's needs are in LDS before it counts as done)
-        if (atomicAdd(&s_acc_done, 1u) == GD_BLOCK / 64 - 1u) {      // the last wave of the block to finish
+        if (atomicAdd(&s_acc_done, 1u) == (TILED ? 2u : 1u) * (GD_BLOCK / 64) - 1u) {      // the last wave of the block to finish (tiled: the counter starts from the eight arrivals above)
             __threadfence_block();
             const unsigned long long t = atomicAdd(&s_acc_cnt, 0ull);
             const unsigned m = atomicMax(&s_acc_max, 0u);

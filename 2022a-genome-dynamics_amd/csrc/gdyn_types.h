@@ -35,7 +35,7 @@
 #define GD_TILED_MAX_W (GD_TILED_MAX_NEAR + GD_TILED_MAX_FAR)
 #define GD_REC_ID_MASK 0x03ffffffu         // bead id field of rec_mo.y; all ones = no bead
 #define GD_DMAX_STRIDE 32u                  // words between the replicas' displacement maxima: one 128-byte line each
-#define GD_REPAIR_GRID 4096u               // blocks of the repair launch behind every k_fill (one k_step wave each; they leave at once while the
+#define GD_REPAIR_GRID 1024u               // blocks of the repair launch behind every k_fill (one k_step wave each; they leave at once while the
                                            // queue is empty); a build that queues more is flagged, and the host launches one block per wave
 #define GD_UNROLL 8u                       // pair-list batch: lists are padded to a multiple of this
 

@@ -212,7 +212,8 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
                     "bead_steps_per_s": N * R * steps / el, "ms_per_step": el / steps * 1e3,
                     "k_step_ms": tm.step_kernel_ms / max(tm.step_launches, 1), "rebuild_ms_per_step": tm.rebuild_ms / max(tm.step_launches, 1),
                     "list_entries_per_bead": c.list_entries / N, "rebuild_interval": int(c.rebuild_interval), "list_radius": c.list_radius,
-                    "rollbacks_in_timed_steps": int(c.rollbacks - rb0), "kernel_path": {0: "none", 1: "generic", 2: "tiled"}[c.list_path]})
+                    "rollbacks_in_timed_steps": int(c.rollbacks - rb0), "kernel_path": {0: "none", 1: "generic", 2: "tiled"}[c.list_path],
+                    "list_GB": c.list_bytes / 1e9, "row_repairs_last_chunk": int(c.row_repairs)})
         tr = _cached_traffic(N, R, c.list_entries / N)
         if tr:      # a committed PMC pass of this workload exists: HBM fraction of its step kernel, as for the headline
             gbs = tr["bytes"] / (out[-1]["k_step_ms"] * 1e-3) / 1e9
@@ -427,7 +428,8 @@ def main():
             "config": {"workload": f"S-genome-{round(N / 1000)}k (5-sim-genome interphase force field, wall dynamics + scale updates on)",
                        "n_beads": N, "replicas_per_gpu": R, "global_replicas": R * world, "parallelism": f"replica-farm x{world}",
                        "timestep": dt, "temperature": kT, "list_entries_per_bead": L_launch / (N * R),
-                       "rebuild_interval": int(ctx.rebuild_interval), "list_radius": ctx.list_radius,
+                       "rebuild_interval": int(ctx.rebuild_interval), "list_radius": ctx.list_radius, "list_GB": ctx.list_bytes / 1e9,
+                       "row_repairs_last_chunk": int(ctx.row_repairs),
                        "rollbacks": int(ctx.rollbacks), "rollbacks_in_timed_steps": int(rollbacks_timed), "equil_steps": a.equil,
                        "steady_state_bead_steps_per_s": N * R * world * n_ss / el_ss, "steady_state_steps": n_ss,
                        "bead_steps_per_s_with_reference_cadence_rank0": obs_rate,

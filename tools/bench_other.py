@@ -42,4 +42,4 @@ t0 = time.perf_counter(); tm = s.run(steps, dt, kT, seed=7, flags=flags); el = t
 c = s.context(); N = info["n_beads"]
 print(json.dumps({"workload": info["workload"], "replicas": R, "bead_steps_per_s": N * R * steps / el, "ms_per_step": el / steps * 1e3,
                   "step_kernel_ms": tm.step_kernel_ms / tm.step_launches, "rebuild_ms_per_step": tm.rebuild_ms / tm.step_launches,
-                  "list_path": c.list_path, "L_per_bead": c.list_entries / N, "list_entries_per_bead": c.list_entries / N, "list_radius": c.list_radius, "K": c.rebuild_interval, "rollbacks": c.rollbacks, "largest_tile": c.largest_tile, "tile_capacity": c.tile_capacity, "E_per_bead": float(s.energy().mean() / N)}))
+                  "list_path": c.list_path, "L_per_bead": c.list_entries / N, "list_entries_per_bead": c.list_entries / N, "list_radius": c.list_radius, "K": c.rebuild_interval, "rollbacks": c.rollbacks, "largest_tile": c.largest_tile, "tile_capacity": c.tile_capacity, "row_repairs_last_chunk": c.row_repairs, "list_GB": c.list_bytes / 1e9, "near_entries_per_bead": c.near_entries / N, "rebuilds": c.rebuilds, "E_per_bead": float(s.energy().mean() / N)}))

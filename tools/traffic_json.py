@@ -29,7 +29,8 @@ for line in open(f"{d}/{tag}{suffix}_bench_pmc_summary.txt"):
     elif cur and re.match(r"(void )?k_(bin|scan|members|scatter|tiles|fill|bbox|gridp)\b", cur):
         m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches\s+(\d+)\s+mean/dispatch\s+([\d.]+)", line)
         if m: build.setdefault(cur.replace("void ", "").split("(")[0], {})[m.group(1)] = float(m.group(3))
-build_bytes = sum((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024 for k, v in build.items() if "bbox" not in k and "gridp" not in k)
+cold = lambda k: "bbox" in k or "gridp" in k or k.startswith("k_bin<false, false>")      # kernels of builds without a box from the build before
+build_bytes = sum((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024 for k, v in build.items() if not cold(k))
 fetch, write = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
 b = (2 * fetch + write) * 1024 * per_step
 if avg_us is not None: avg_us *= per_step
@@ -44,6 +45,6 @@ out = {"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate pa
                   "wait_fraction_of_wave_cycles": vals.get("SQ_WAIT_ANY", (0, 0))[0] / max(vals.get("SQ_WAVE_CYCLES", (1, 0))[0], 1),
                   "lds_bank_conflict_fraction": vals.get("SQ_LDS_BANK_CONFLICT", (0, 0))[0] / max(vals.get("SQ_LDS_IDX_ACTIVE", (1, 0))[0], 1)}}
 out["build"] = {"corrected_bytes_per_build": build_bytes, "kernels": {k: (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024 for k, v in build.items()},
-                "_comment": "2 x FETCH_SIZE + WRITE_SIZE of every kernel of the list build chain (warm builds: k_bbox / k_gridp not counted), per build"}
+                "_comment": "2 x FETCH_SIZE + WRITE_SIZE of every kernel of the list build chain (warm builds: k_bbox / k_gridp / the cold k_bin not counted), per build"}
 json.dump(out, open(f"profiles/{tag}_traffic{suffix}.json", "w"), indent=1)
 print(json.dumps(out["k_step"]))
