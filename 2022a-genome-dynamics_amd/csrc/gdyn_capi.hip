@@ -1287,12 +1287,12 @@ static void class_skin(gd_system *s, const gd_run_desc *run)
         const double cut = pair_cutoff(s), sc0 = s->rv / cut - s->skin, ratio = (sc0 + s->skin_dense_from) / (sc0 + s->skin);
         // (narrowed for the memory of the rows: back when the longest list, scaled with the cube of the radius, fits the budget again;
         // narrowed for the LDS tile: back -- in steps of at most a quarter of the width, the densest tile decides -- when the largest
-        // tile, scaled with the square of the radius, fits 0.7 of the LDS)
+        // tile, scaled with the square of the radius, fits 0.85 of the LDS)
         if (s->dense_by_tile) {
             if (s->list_tiled && s->last_need_t > 0 && !(s->skin_next > 0)) {
-                const double target = std::min(s->skin_dense_from, s->skin * 1.25 + 0.02);
+                const double target = std::min(s->skin_dense_from, s->skin * 1.35 + 0.02);
                 const double rt = (sc0 + target) / (sc0 + s->skin);
-                if ((double)s->last_need_t * rt * rt <= 0.7 * 8192.0) {
+                if ((double)s->last_need_t * rt * rt <= 0.85 * 8192.0) {      // (a decondensing globule: the tiles shrink from build to build; a miss costs one rolled-back chunk)
                     s->skin_next = target;
                     if (target >= s->skin_dense_from - 1e-9) { s->skin_dense_from = 0; s->dense_by_tile = false; }
                     if (dev_env("GDYN_DEBUG")) fprintf(stderr, "[gdyn] dense state eases (largest tile %u): skin %.3f at the next build\n", s->last_need_t, s->skin_next);

@@ -1355,3 +1355,41 @@ def test_ragged_rows_globule_and_gas_in_one_handle(hip, oracle):
         so.set_positions(x[r]); so.begin_phase()
         so.run(12, 2e-6, 1.0, seed=[5, 6][r])
         assert np.abs(x1[r] - so.positions()[0]).max() <= POS_ATOL_20STEP
+
+
+def test_fine_timestep_with_the_droplet_term_keeps_its_share_of_the_displacement(hip, oracle):
+    """The compensated update covers the droplet kernel too (round 5): gd_fine_sampling's force field includes the nucleolar droplet
+    attraction when nucleolus_droplet_energy != 0 (simulation_driver_forcefield.cc:153-178), and at T = 0, dt = 1e-7 the droplet's share of
+    mu F dt on a nucleolar bead is around or below an ulp of its coordinate -- added in plain fp32 behind k_step it was rounded away.
+    300 steps, device vs oracle, on the displacement of the TARGET beads: within 1e-3 of their median displacement; with the droplet
+    force switched off on the device only, the same bound fails (so the test sees the term)."""
+    n, nt = 6000, 300
+    rng = np.random.default_rng(4)
+    tg = np.sort(rng.choice(n, size=nt, replace=False))
+    s0, info = wl.genome_interphase(hip, n_beads=n)
+    s0.begin_phase()
+    s0.run(2000, info["timestep"], info["temperature"], seed=SEED + 3, flags=0)
+    x0 = s0.positions()
+    s0.close()
+    x0[0, tg] = x0[0, tg[0]] + 0.3 * rng.normal(size=(nt, 3))           # a clump of targets: many droplet pairs in range
+    x0 = x0.astype(np.float32).astype(np.float64)
+    def run(lib, energy):
+        s, _ = wl.genome_interphase(lib, n_beads=n)
+        s.set_pair_softwell(energy, 0.2, 0.4, tg)
+        s.set_positions(x0)
+        s.begin_phase()
+        s.run(300, 1e-7, 0.0, seed=1, flags=g.RUN_WALL_DYNAMICS)
+        comp = s.context().compensated
+        d = s.positions()[0] - x0[0]
+        s.close()
+        return d, comp
+    do, _ = run(oracle, 0.05)
+    do0, _ = run(oracle, 0.0)
+    share = np.abs(do[tg] - do0[tg])                       # what the droplet term contributes to the targets' displacement
+    med = np.median(np.abs(do[tg]))
+    assert np.median(share) > 1e-8 and np.median(share) < 0.2 * med, (np.median(share), med)      # a small share: the part plain fp32 drops
+    dh, comp = run(hip, 0.05)
+    assert comp == 1
+    err = np.abs(dh[tg] - do[tg])
+    assert err.max() <= 1e-3 * med, (err.max(), med)
+    assert np.abs(dh[tg] - do0[tg]).max() > 3 * err.max()          # (without the term the targets would be off by its share)
