@@ -286,3 +286,24 @@ def test_every_entry_point_makes_its_device_current_before_its_first_hip_call():
         assert sets and sets.start() <= uses.start(), name
         checked += 1
     assert checked >= 12
+
+
+def test_committed_pmc_traffic_describes_the_kernel_source_in_the_tree():
+    """bench.py exits with status 4 when the committed PMC traffic of the headline workload was taken from another kernel source
+    (hash of gdyn_kernels.hip + gdyn_types.h): a kernel edit without a new profile round must fail HERE, on the CPU, not in the
+    driver's bench run."""
+    import glob
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = bench._kernel_source_sha()
+    matches = []
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")):
+        tj = json.load(open(path))
+        if tj.get("workload") == {"n_beads": 30000, "replicas_per_gpu": 128} and tj.get("kernel_source_sha") == sha:
+            matches.append(path)
+    assert matches, f"no profiles/r*_traffic.json for kernel source {sha}: run tools/profile_round.sh and tools/traffic_json.py"
+    tr = bench._cached_traffic(30000, 128, json.load(open(matches[0]))["list_entries_per_bead"])
+    assert tr and tr["bytes"] > 1e8 and tr["build_bytes"] > 1e8
