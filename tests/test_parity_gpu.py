@@ -1393,3 +1393,29 @@ def test_fine_timestep_with_the_droplet_term_keeps_its_share_of_the_displacement
     err = np.abs(dh[tg] - do[tg])
     assert err.max() <= 1e-3 * med, (err.max(), med)
     assert np.abs(dh[tg] - do0[tg]).max() > 3 * err.max()          # (without the term the targets would be off by its share)
+
+
+def test_rows_recover_from_a_first_guess_that_is_far_too_small(hip, oracle):
+    """Ragged rows without history start from the caller's guess (gd_tuning.list_width).  A guess of 8 entries where the lists hold ~30
+    makes EVERY k_step wave outgrow its rows at the first build: more waves than the repair launch has blocks -- flagged, the build is
+    repeated with a repair block per wave and a pool sized from what the cursor counted -- and the handle ends up with exact rows:
+    forces and pair set as the oracle's, then a run without a rollback for a row."""
+    n, R = 8000, 2
+    sh, info = wl.genome_interphase(hip, n_beads=n, n_replicas=R)
+    so, _ = wl.genome_interphase(oracle, n_beads=n, n_replicas=R)
+    sh.set_tuning(kernel_path=2, list_width=8)
+    x = sh.positions()
+    Fh, Fo = sh.forces(), so.forces()
+    assert sh.context().list_path == 2
+    assert np.abs(Fh - Fo).max() <= FORCE_RTOL * np.abs(Fo).max()
+    for r in range(R):
+        ph = {tuple(p) for p in sh.search_pairs(0.3, replica=r)}
+        po = {tuple(p) for p in so.search_pairs(0.3, replica=r)}
+        for i, j in ph ^ po:
+            assert abs(np.linalg.norm(x[r][i] - x[r][j]) - 0.3) < 1e-6
+    c0 = sh.context()
+    assert c0.list_bytes > 0 and c0.list_entries / n > 15
+    for s in (sh, so):
+        s.begin_phase()
+        s.run(20, info["timestep"], info["temperature"], seed=SEED, flags=g.RUN_UPDATE_SCALES | g.RUN_WALL_DYNAMICS)
+    assert np.abs(sh.positions() - so.positions()).max() <= POS_ATOL_20STEP

@@ -21,4 +21,4 @@ while done < total:
     c = s.context()
     x = s.positions_f32()
     print(f"step {done:6d}  {30000 * R * 2000 / el / 1e9:6.2f} G bead-steps/s  path {c.list_path}  K {c.rebuild_interval:3d}  L {c.list_entries / 30000:5.1f}  "
-          f"rollbacks {c.rollbacks}  R_wall {c.semiaxes[0]:.4f}  E/bead {s.energy()[0] / 30000:.4f}  finite {bool(np.isfinite(x).all())}", flush=True)
+          f"rollbacks {c.rollbacks}  lists {c.list_bytes / 1e9:.2f} GB  repairs {c.row_repairs}  R_wall {c.semiaxes[0]:.4f}  E/bead {s.energy()[0] / 30000:.4f}  finite {bool(np.isfinite(x).all())}", flush=True)
