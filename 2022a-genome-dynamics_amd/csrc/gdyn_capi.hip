@@ -601,7 +601,7 @@ extern "C" int gd_set_tuning(gd_system *s, const gd_tuning *t)
     if (t->near_fraction < 0 || t->near_fraction > 1) return fail(GD_EINVAL, "gd_set_tuning: near_fraction must be in [0,1]");
     HIPCHK(hipSetDevice(s->device));
     if (t->skin > 0) { s->skin = t->skin; s->skin_fixed = true; }
-    else if (t->skin < 0) { s->skin = 0.75; s->skin_fixed = false; s->skin_dense_from = 0; }      // back to the library's own choice
+    else if (t->skin < 0) { s->skin = 0.75; s->skin_fixed = false; s->skin_dense_from = 0; s->dense_by_tile = false; }      // back to the library's own choice
     s->skin_streak = 0; s->skin_hold = 0; s->skin_next = 0;
     if (t->rebuild_interval > 0) s->K = t->rebuild_interval;
     s->tuner = gd_system::SkinTuner{};
