@@ -202,7 +202,9 @@ def other_workloads(g, wl, hip, dev_index, budget_steps=600):
                         break
                     relax += 1000
             s.begin_phase()
-        s.run(max(steps // 4, 40), dt, kT, seed=6, flags=flags)
+        # (the relaxation ran with static scales and wall: the timed phase's flags switch the wall dynamics on, and the interval has to
+        # re-adapt on complete intervals of THAT regime -- two chunks of twelve intervals, as the headline does before its window)
+        s.run(max(steps // 4, 40, 24 * int(s.context().rebuild_interval)), dt, kT, seed=6, flags=flags)
         rb0 = s.context().rollbacks
         t0 = time.perf_counter()
         tm = s.run(steps, dt, kT, seed=7, flags=flags)
