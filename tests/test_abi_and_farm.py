@@ -224,6 +224,12 @@ def test_per_device_setup_guard_runs_once_per_device_and_blocks_until_done(tmp_p
                            os.path.join(ROOT, "tests", "native", "test_once.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "once: ok" in out.stdout, out.stdout + out.stderr
+    # the same under ThreadSanitizer (sanitizers run on the CPU builds only): no report
+    exe_t = str(tmp_path / "test_once_tsan")
+    if subprocess.call(["g++", "-O1", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", os.path.join(ROOT, PKG_DIR, "csrc"), "-o", exe_t,
+                        os.path.join(ROOT, "tests", "native", "test_once.cpp")], stderr=subprocess.DEVNULL) == 0:
+        out = subprocess.run([exe_t], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "once: ok" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr
 
 
 def test_no_launcher_keeps_an_unsynchronised_once_flag():
